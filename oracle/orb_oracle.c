@@ -1,0 +1,1242 @@
+/*
+ * orb_oracle.c -- CPU restatement of the GF-ORB-SLAM2 ORB front-end (see orb_oracle.h).
+ *
+ * TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (the reference has no golden
+ * vectors for this path and OpenCV 3.4.1 cannot be run here).
+ *
+ * Build with -ffp-contract=off: every float expression below is meant to be
+ * evaluated as written (one IEEE-754 rounding per operation), which is also
+ * what the GPU kernels do.
+ */
+#include "orb_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------- */
+/* OpenCV 3.4.1 semantics: scalar helpers                                     */
+/* ------------------------------------------------------------------------- */
+
+/* cvRound(float/double): round-half-to-even (SSE cvtss2si / lrint). */
+static int cv_round_f(float v) { return (int)lrintf(v); }
+static int cv_round_d(double v) { return (int)lrint(v); }
+static int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+static int cv_ceil_f(float v) { int i = (int)v; return i + (i < v); }
+static short sat_short(int v) { return (short)(v < -32768 ? -32768 : v > 32767 ? 32767 : v); }
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
+static int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) {
+        if (p < 0) p = -p;
+        else p = 2 * len - 2 - p;
+    }
+    return p;
+}
+
+static const int g_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+const int *oo_pattern(void) { return g_pattern; }
+
+/* ------------------------------------------------------------------------- */
+/* Extractor object and constructor tables                                    */
+/* ------------------------------------------------------------------------- */
+
+struct oo_extractor {
+    int nfeatures, nlevels, iniTh, minTh;
+    double scaleFactor; /* the reference keeps this member as double (include/ORBextractor.h:163) */
+    float scale[OO_MAX_LEVELS], inv_scale[OO_MAX_LEVELS];
+    float sigma2[OO_MAX_LEVELS], inv_sigma2[OO_MAX_LEVELS];
+    int nfeat[OO_MAX_LEVELS];
+    int umax[OO_HALF_PATCH + 2];
+    /* pyramid of the last ComputePyramid call */
+    uint8_t *plane[OO_MAX_LEVELS];
+    int lw[OO_MAX_LEVELS], lh[OO_MAX_LEVELS];
+    int level_counts[OO_MAX_LEVELS];
+};
+
+/* src/ORBextractor.cc:967-1026 */
+oo_extractor *oo_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
+{
+    if (nlevels < 1 || nlevels > OO_MAX_LEVELS) return NULL;
+    oo_extractor *ex = (oo_extractor *)calloc(1, sizeof(*ex));
+    ex->nfeatures = nfeatures;
+    ex->scaleFactor = scaleFactor;
+    ex->nlevels = nlevels;
+    ex->iniTh = iniThFAST;
+    ex->minTh = minThFAST;
+
+    ex->scale[0] = 1.0f;
+    ex->sigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) {
+        ex->scale[i] = (float)(ex->scale[i - 1] * ex->scaleFactor); /* :977 float*double */
+        ex->sigma2[i] = ex->scale[i] * ex->scale[i];
+    }
+    for (int i = 0; i < nlevels; i++) {
+        ex->inv_scale[i] = 1.0f / ex->scale[i];
+        ex->inv_sigma2[i] = 1.0f / ex->sigma2[i];
+    }
+
+    float factor = (float)(1.0f / ex->scaleFactor); /* :992 */
+    float nDesired = nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        ex->nfeat[level] = cv_round_f(nDesired);
+        sum += ex->nfeat[level];
+        nDesired *= factor;
+    }
+    ex->nfeat[nlevels - 1] = imax(nfeatures - sum, 0);
+
+    /* :1010-1025 end of each row of the circular patch */
+    int v, v0;
+    int vmax = cv_floor_f(OO_HALF_PATCH * sqrtf(2.f) / 2 + 1);
+    int vmin = cv_ceil_f(OO_HALF_PATCH * sqrtf(2.f) / 2);
+    const double hp2 = OO_HALF_PATCH * OO_HALF_PATCH;
+    for (v = 0; v <= vmax; ++v) ex->umax[v] = cv_round_d(sqrt(hp2 - v * v));
+    for (v = OO_HALF_PATCH, v0 = 0; v >= vmin; --v) {
+        while (ex->umax[v0] == ex->umax[v0 + 1]) ++v0;
+        ex->umax[v] = v0;
+        ++v0;
+    }
+    return ex;
+}
+
+void oo_destroy(oo_extractor *ex)
+{
+    if (!ex) return;
+    for (int i = 0; i < OO_MAX_LEVELS; i++) free(ex->plane[i]);
+    free(ex);
+}
+
+void oo_get_tables(const oo_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                   float *inv_sigma2, int *nfeat_per_level, int *umax16)
+{
+    for (int i = 0; i < ex->nlevels; i++) {
+        if (scale) scale[i] = ex->scale[i];
+        if (inv_scale) inv_scale[i] = ex->inv_scale[i];
+        if (sigma2) sigma2[i] = ex->sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = ex->inv_sigma2[i];
+        if (nfeat_per_level) nfeat_per_level[i] = ex->nfeat[i];
+    }
+    if (umax16) for (int i = 0; i <= OO_HALF_PATCH; i++) umax16[i] = ex->umax[i];
+}
+
+void oo_level_size(const oo_extractor *ex, int w, int h, int level, int *lw, int *lh)
+{
+    float scale = ex->inv_scale[level]; /* :1196-1197 */
+    *lw = cv_round_f((float)w * scale);
+    *lh = cv_round_f((float)h * scale);
+}
+
+/* ------------------------------------------------------------------------- */
+/* OpenCV 3.4.1 semantics: cv::resize(INTER_LINEAR) on 8UC1                   */
+/* generic path: resizeGeneric_ + HResizeLinear + VResizeLinear<uchar,int,    */
+/* short,FixedPtCast<int,uchar,22>>; INTER_RESIZE_COEF_BITS = 11.             */
+/* ------------------------------------------------------------------------- */
+void oo_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
+                         uint8_t *dst, int dw, int dh, int dstride)
+{
+    double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    int *xofs = (int *)malloc(sizeof(int) * dw);
+    short *ialpha = (short *)malloc(sizeof(short) * 2 * dw);
+    int *hrow0 = (int *)malloc(sizeof(int) * dw);
+    int *hrow1 = (int *)malloc(sizeof(int) * dw);
+
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = cv_floor_f(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        xofs[dx] = sx;
+        ialpha[2 * dx] = sat_short(cv_round_f((1.f - fx) * 2048));
+        ialpha[2 * dx + 1] = sat_short(cv_round_f(fx * 2048));
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = cv_floor_f(fy);
+        fy -= sy;
+        short b0 = sat_short(cv_round_f((1.f - fy) * 2048));
+        short b1 = sat_short(cv_round_f(fy * 2048));
+        /* rows sy and sy+1, each clipped into [0, sh-1] */
+        int y0 = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+        const uint8_t *S0 = src + (size_t)y0 * sstride, *S1 = src + (size_t)y1 * sstride;
+        for (int dx = 0; dx < dw; dx++) {
+            int sx = xofs[dx];
+            int sx1 = sx + 1 < sw ? sx + 1 : sx; /* weight is 0 there */
+            hrow0[dx] = S0[sx] * ialpha[2 * dx] + S0[sx1] * ialpha[2 * dx + 1];
+            hrow1[dx] = S1[sx] * ialpha[2 * dx] + S1[sx1] * ialpha[2 * dx + 1];
+        }
+        uint8_t *D = dst + (size_t)dy * dstride;
+        for (int dx = 0; dx < dw; dx++)
+            D[dx] = (uint8_t)((((b0 * (hrow0[dx] >> 4)) >> 16) + ((b1 * (hrow1[dx] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(ialpha); free(hrow0); free(hrow1);
+}
+
+/* copyMakeBorder(REFLECT_101) in place around the level image of a bordered plane */
+static void fill_border_reflect101(uint8_t *plane, int w, int h)
+{
+    const int B = OO_EDGE_THRESHOLD, bw = w + 2 * B, bh = h + 2 * B;
+    for (int y = 0; y < bh; y++) {
+        int sy = reflect101(y - B, h);
+        uint8_t *row = plane + (size_t)y * bw;
+        const uint8_t *srow = plane + (size_t)(sy + B) * bw;
+        for (int x = 0; x < bw; x++) {
+            if (y >= B && y < B + h && x >= B && x < B + w) continue;
+            row[x] = srow[reflect101(x - B, w) + B];
+        }
+    }
+}
+
+/* src/ORBextractor.cc:1192-1216 */
+int oo_compute_pyramid(oo_extractor *ex, const uint8_t *img, int w, int h, int stride)
+{
+    const int B = OO_EDGE_THRESHOLD;
+    for (int level = 0; level < ex->nlevels; level++) {
+        int lw, lh;
+        oo_level_size(ex, w, h, level, &lw, &lh);
+        if (lw < 1 || lh < 1) return -1;
+        ex->lw[level] = lw;
+        ex->lh[level] = lh;
+        free(ex->plane[level]);
+        int bw = lw + 2 * B, bh = lh + 2 * B;
+        ex->plane[level] = (uint8_t *)calloc((size_t)bw * bh, 1);
+        uint8_t *roi = ex->plane[level] + (size_t)B * bw + B;
+        if (level != 0) {
+            int pbw = ex->lw[level - 1] + 2 * B;
+            const uint8_t *proi = ex->plane[level - 1] + (size_t)B * pbw + B;
+            oo_resize_linear_u8(proi, ex->lw[level - 1], ex->lh[level - 1], pbw, roi, lw, lh, bw);
+        } else {
+            for (int y = 0; y < h; y++) memcpy(roi + (size_t)y * bw, img + (size_t)y * stride, w);
+        }
+        fill_border_reflect101(ex->plane[level], lw, lh);
+    }
+    return 0;
+}
+
+const uint8_t *oo_pyramid_plane(const oo_extractor *ex, int level, int *bw, int *bh)
+{
+    if (bw) *bw = ex->lw[level] + 2 * OO_EDGE_THRESHOLD;
+    if (bh) *bh = ex->lh[level] + 2 * OO_EDGE_THRESHOLD;
+    return ex->plane[level];
+}
+
+/* ------------------------------------------------------------------------- */
+/* OpenCV 3.4.1 semantics: cv::FAST TYPE_9_16 with non-max suppression        */
+/* (features2d/src/fast.cpp FAST_t<16>, fast_score.cpp cornerScore<16>;       */
+/* in-repo restatement of the same structure: src/FAST_NEON.cc:91-287)        */
+/* ------------------------------------------------------------------------- */
+static const int g_ring[16][2] = { /* src/FAST_NEON.cc:3-7: Bresenham circle r=3 */
+    {0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3},
+    {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+
+static void make_offsets(int pixel[25], int stride)
+{
+    int k = 0;
+    for (; k < 16; k++) pixel[k] = g_ring[k][0] + g_ring[k][1] * stride;
+    for (; k < 25; k++) pixel[k] = pixel[k - 16];
+}
+
+/* cornerScore<16>: largest threshold for which the pixel is still a corner */
+static int corner_score16(const uint8_t *ptr, const int pixel[25], int threshold)
+{
+    const int N = 25;
+    int k, v = ptr[0];
+    short d[25];
+    for (k = 0; k < N; k++) d[k] = (short)(v - ptr[pixel[k]]);
+
+    int a0 = threshold;
+    for (k = 0; k < 16; k += 2) {
+        int a = imin((int)d[k + 1], (int)d[k + 2]);
+        a = imin(a, (int)d[k + 3]);
+        if (a <= a0) continue;
+        a = imin(a, (int)d[k + 4]);
+        a = imin(a, (int)d[k + 5]);
+        a = imin(a, (int)d[k + 6]);
+        a = imin(a, (int)d[k + 7]);
+        a = imin(a, (int)d[k + 8]);
+        a0 = imax(a0, imin(a, (int)d[k]));
+        a0 = imax(a0, imin(a, (int)d[k + 9]));
+    }
+    int b0 = -a0;
+    for (k = 0; k < 16; k += 2) {
+        int b = imax((int)d[k + 1], (int)d[k + 2]);
+        b = imax(b, (int)d[k + 3]);
+        b = imax(b, (int)d[k + 4]);
+        b = imax(b, (int)d[k + 5]);
+        if (b >= b0) continue;
+        b = imax(b, (int)d[k + 6]);
+        b = imax(b, (int)d[k + 7]);
+        b = imax(b, (int)d[k + 8]);
+        b0 = imin(b0, imax(b, (int)d[k]));
+        b0 = imin(b0, imax(b, (int)d[k + 9]));
+    }
+    return -b0 - 1;
+}
+
+int oo_fast9_nms(const uint8_t *img, int w, int h, int stride, int threshold, oo_cand *out, int cap)
+{
+    const int K = 8, N = 25;
+    int i, j, k, pixel[25], nout = 0;
+    make_offsets(pixel, stride);
+    threshold = imin(imax(threshold, 0), 255);
+
+    uint8_t threshold_tab[512];
+    for (i = -255; i <= 255; i++)
+        threshold_tab[i + 255] = (uint8_t)(i < -threshold ? 1 : i > threshold ? 2 : 0);
+
+    if (w < 1 || h < 1) return 0;
+    uint8_t *bufmem = (uint8_t *)calloc((size_t)w * 3, 1);
+    int *cpmem = (int *)calloc((size_t)(w + 1) * 3, sizeof(int));
+    uint8_t *buf[3] = {bufmem, bufmem + w, bufmem + 2 * w};
+    int *cpbuf[3] = {cpmem + 1, cpmem + 1 + (w + 1), cpmem + 1 + 2 * (w + 1)};
+
+    for (i = 3; i < h - 2; i++) {
+        const uint8_t *ptr = img + (size_t)i * stride + 3;
+        uint8_t *curr = buf[(i - 3) % 3];
+        int *cornerpos = cpbuf[(i - 3) % 3];
+        memset(curr, 0, w);
+        int ncorners = 0;
+
+        if (i < h - 3) {
+            for (j = 3; j < w - 3; j++, ptr++) {
+                int v = ptr[0];
+                const uint8_t *tab = &threshold_tab[0] - v + 255;
+                int d = tab[ptr[pixel[0]]] | tab[ptr[pixel[8]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[2]]] | tab[ptr[pixel[10]]];
+                d &= tab[ptr[pixel[4]]] | tab[ptr[pixel[12]]];
+                d &= tab[ptr[pixel[6]]] | tab[ptr[pixel[14]]];
+                if (d == 0) continue;
+                d &= tab[ptr[pixel[1]]] | tab[ptr[pixel[9]]];
+                d &= tab[ptr[pixel[3]]] | tab[ptr[pixel[11]]];
+                d &= tab[ptr[pixel[5]]] | tab[ptr[pixel[13]]];
+                d &= tab[ptr[pixel[7]]] | tab[ptr[pixel[15]]];
+
+                if (d & 1) {
+                    int vt = v - threshold, count = 0;
+                    for (k = 0; k < N; k++) {
+                        int x = ptr[pixel[k]];
+                        if (x < vt) {
+                            if (++count > K) {
+                                cornerpos[ncorners++] = j;
+                                curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                                break;
+                            }
+                        } else
+                            count = 0;
+                    }
+                }
+                if (d & 2) {
+                    int vt = v + threshold, count = 0;
+                    for (k = 0; k < N; k++) {
+                        int x = ptr[pixel[k]];
+                        if (x > vt) {
+                            if (++count > K) {
+                                cornerpos[ncorners++] = j;
+                                curr[j] = (uint8_t)corner_score16(ptr, pixel, threshold);
+                                break;
+                            }
+                        } else
+                            count = 0;
+                    }
+                }
+            }
+        }
+        cornerpos[-1] = ncorners;
+        if (i == 3) continue;
+
+        const uint8_t *prev = buf[(i - 4 + 3) % 3];
+        const uint8_t *pprev = buf[(i - 5 + 3) % 3];
+        cornerpos = cpbuf[(i - 4 + 3) % 3];
+        ncorners = cornerpos[-1];
+        for (k = 0; k < ncorners; k++) {
+            j = cornerpos[k];
+            int score = prev[j];
+            if (score > prev[j + 1] && score > prev[j - 1] &&
+                score > pprev[j - 1] && score > pprev[j] && score > pprev[j + 1] &&
+                score > curr[j - 1] && score > curr[j] && score > curr[j + 1]) {
+                if (nout < cap) {
+                    out[nout].x = j;
+                    out[nout].y = i - 1;
+                    out[nout].response = score;
+                }
+                nout++;
+            }
+        }
+    }
+    free(bufmem);
+    free(cpmem);
+    return nout;
+}
+
+/* Independent derivation: S(p) = max over the 16 arcs A of 9 contiguous ring
+ * pixels of max(min_{q in A}(I(p)-I(q)), min_{q in A}(I(q)-I(p))) - 1.
+ * "p is a corner at threshold t" <=> S(p) >= t, and the stored score is S(p). */
+int oo_fast_score_bruteforce(const uint8_t *center, int stride)
+{
+    int v = center[0], best = -1000;
+    for (int s = 0; s < 16; s++) {
+        int mn_dark = 1000, mn_bright = 1000;
+        for (int j = 0; j < 9; j++) {
+            int k = (s + j) & 15;
+            int p = center[g_ring[k][0] + g_ring[k][1] * stride];
+            mn_dark = imin(mn_dark, v - p);
+            mn_bright = imin(mn_bright, p - v);
+        }
+        best = imax(best, imax(mn_dark, mn_bright));
+    }
+    return best - 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Cell loop of ComputeKeyPointsOctTree, src/ORBextractor.cc:1036-1101        */
+/* ------------------------------------------------------------------------- */
+static int detect_level_literal(const oo_extractor *ex, int level, oo_cand *out, int cap)
+{
+    const int B = OO_EDGE_THRESHOLD;
+    const int cols = ex->lw[level], rows = ex->lh[level];
+    const int pitch = cols + 2 * B;
+    const uint8_t *im = ex->plane[level] + (size_t)B * pitch + B;
+    const float W = 30;
+    const int minBorderX = OO_EDGE_THRESHOLD - 3, minBorderY = minBorderX;
+    const int maxBorderX = cols - OO_EDGE_THRESHOLD + 3, maxBorderY = rows - OO_EDGE_THRESHOLD + 3;
+    const float width = (float)(maxBorderX - minBorderX), height = (float)(maxBorderY - minBorderY);
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols < 1 || nRows < 1) return 0; /* reference would divide by zero */
+    const int wCell = (int)ceilf(width / nCols), hCell = (int)ceilf(height / nRows);
+    int nout = 0;
+    int cellcap = (wCell + 6) * (hCell + 6);
+    oo_cand *cell = (oo_cand *)malloc(sizeof(oo_cand) * cellcap);
+
+    for (int i = 0; i < nRows; i++) {
+        const float iniY = (float)(minBorderY + i * hCell);
+        float maxY = iniY + hCell + 6;
+        if (iniY >= maxBorderY - 3) continue;
+        if (maxY > maxBorderY) maxY = (float)maxBorderY;
+        for (int j = 0; j < nCols; j++) {
+            const float iniX = (float)(minBorderX + j * wCell);
+            float maxX = iniX + wCell + 6;
+            if (iniX >= maxBorderX - 6) continue;
+            if (maxX > maxBorderX) maxX = (float)maxBorderX;
+            int x0 = (int)iniX, x1 = (int)maxX, y0 = (int)iniY, y1 = (int)maxY;
+            const uint8_t *sub = im + (size_t)y0 * pitch + x0;
+            int n = oo_fast9_nms(sub, x1 - x0, y1 - y0, pitch, ex->iniTh, cell, cellcap);
+            if (n == 0) n = oo_fast9_nms(sub, x1 - x0, y1 - y0, pitch, ex->minTh, cell, cellcap);
+            for (int k = 0; k < n; k++) {
+                if (nout < cap) {
+                    out[nout].x = cell[k].x + j * wCell;
+                    out[nout].y = cell[k].y + i * hCell;
+                    out[nout].response = cell[k].response;
+                }
+                nout++;
+            }
+        }
+    }
+    free(cell);
+    return nout;
+}
+
+/* Single-pass equivalent: one threshold-free score image; in-cell strict
+ * local maxima with S >= minTh; a cell that owns a maximum with S >= iniTh
+ * keeps only those. The tested areas of the cells tile
+ * [3,width-3) x [3,height-3) (coordinates relative to (16,16)). */
+static int detect_level_scoremap(const oo_extractor *ex, int level, oo_cand *out, int cap)
+{
+    const int B = OO_EDGE_THRESHOLD;
+    const int cols = ex->lw[level], rows = ex->lh[level];
+    const int pitch = cols + 2 * B;
+    const uint8_t *im = ex->plane[level] + (size_t)B * pitch + B;
+    const int width = cols - 2 * 16, height = rows - 2 * 16;
+    const int nCols = (int)((float)width / 30.f), nRows = (int)((float)height / 30.f);
+    if (nCols < 1 || nRows < 1) return 0;
+    const int wCell = (int)ceilf((float)width / nCols), hCell = (int)ceilf((float)height / nRows);
+    int thr_min = imin(imax(ex->minTh, 0), 255), thr_ini = imin(imax(ex->iniTh, 0), 255);
+    int nout = 0;
+    if (width < 7 || height < 7) return 0;
+
+    /* score image over relative coordinates, zero outside [3,width-3)x[3,height-3) */
+    uint8_t *S = (uint8_t *)calloc((size_t)width * height, 1);
+    for (int y = 3; y < height - 3; y++)
+        for (int x = 3; x < width - 3; x++) {
+            int s = oo_fast_score_bruteforce(im + (size_t)(y + 16) * pitch + (x + 16), pitch);
+            S[(size_t)y * width + x] = (uint8_t)((s >= thr_min && s > 0) ? s : 0);
+        }
+    /* a corner with S == 0 (only possible for threshold 0) is stored as 0 and can
+     * never be a strict maximum over zero neighbours -- same as the literal path */
+
+    for (int ci = 0; ci < nRows; ci++) {
+        int ty0 = ci * hCell + 3, ty1 = imin((ci + 1) * hCell + 3, height - 3);
+        for (int cj = 0; cj < nCols; cj++) {
+            int tx0 = cj * wCell + 3, tx1 = imin((cj + 1) * wCell + 3, width - 3);
+            if (ty0 >= ty1 || tx0 >= tx1) continue;
+            int any_ini = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                for (int y = ty0; y < ty1; y++)
+                    for (int x = tx0; x < tx1; x++) {
+                        int s = S[(size_t)y * width + x];
+                        if (s == 0) continue;
+                        int ok = 1;
+                        for (int dy = -1; dy <= 1 && ok; dy++)
+                            for (int dx = -1; dx <= 1; dx++) {
+                                if (!dx && !dy) continue;
+                                int xx = x + dx, yy = y + dy;
+                                int q = (xx >= tx0 && xx < tx1 && yy >= ty0 && yy < ty1)
+                                            ? S[(size_t)yy * width + xx] : 0;
+                                if (!(s > q)) { ok = 0; break; }
+                            }
+                        if (!ok) continue;
+                        if (pass == 0) {
+                            if (s >= thr_ini) any_ini = 1;
+                        } else if (!any_ini || s >= thr_ini) {
+                            if (nout < cap) {
+                                out[nout].x = x;
+                                out[nout].y = y;
+                                out[nout].response = s;
+                            }
+                            nout++;
+                        }
+                    }
+            }
+        }
+    }
+    free(S);
+    return nout;
+}
+
+int oo_detect_level(const oo_extractor *ex, int level, int literal, oo_cand *out, int cap)
+{
+    return literal ? detect_level_literal(ex, level, out, cap) : detect_level_scoremap(ex, level, out, cap);
+}
+
+/* ------------------------------------------------------------------------- */
+/* DistributeOctTree -- literal std::list emulation                           */
+/* src/ORBextractor.cc:488-711, ExtractorNode::DivideNode :431-486            */
+/* ------------------------------------------------------------------------- */
+typedef struct lnode {
+    int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+    int *keys;
+    int nkeys;
+    int noMore;
+    long addr; /* creation sequence number: stand-in for the heap address */
+    struct lnode *prev, *next;
+} lnode;
+
+typedef struct { lnode *head, *tail; int size; long next_addr; } llist;
+
+static lnode *node_new(int cap)
+{
+    lnode *n = (lnode *)calloc(1, sizeof(lnode));
+    n->keys = (int *)malloc(sizeof(int) * (cap > 0 ? cap : 1));
+    return n;
+}
+static void node_free(lnode *n) { free(n->keys); free(n); }
+static void list_push_front(llist *l, lnode *n)
+{
+    n->addr = l->next_addr++;
+    n->prev = NULL; n->next = l->head;
+    if (l->head) l->head->prev = n; else l->tail = n;
+    l->head = n; l->size++;
+}
+static void list_push_back(llist *l, lnode *n)
+{
+    n->addr = l->next_addr++;
+    n->next = NULL; n->prev = l->tail;
+    if (l->tail) l->tail->next = n; else l->head = n;
+    l->tail = n; l->size++;
+}
+static lnode *list_erase(llist *l, lnode *n) /* returns next */
+{
+    lnode *nx = n->next;
+    if (n->prev) n->prev->next = n->next; else l->head = n->next;
+    if (n->next) n->next->prev = n->prev; else l->tail = n->prev;
+    l->size--;
+    node_free(n);
+    return nx;
+}
+
+static void divide_node(const lnode *p, const oo_cand *c, lnode *ch[4])
+{
+    const int halfX = (int)ceilf((float)(p->URx - p->ULx) / 2);
+    const int halfY = (int)ceilf((float)(p->BRy - p->ULy) / 2);
+    lnode *n1 = ch[0] = node_new(p->nkeys), *n2 = ch[1] = node_new(p->nkeys);
+    lnode *n3 = ch[2] = node_new(p->nkeys), *n4 = ch[3] = node_new(p->nkeys);
+    n1->ULx = p->ULx; n1->ULy = p->ULy;
+    n1->URx = p->ULx + halfX; n1->URy = p->ULy;
+    n1->BLx = p->ULx; n1->BLy = p->ULy + halfY;
+    n1->BRx = p->ULx + halfX; n1->BRy = p->ULy + halfY;
+
+    n2->ULx = n1->URx; n2->ULy = n1->URy;
+    n2->URx = p->URx; n2->URy = p->URy;
+    n2->BLx = n1->BRx; n2->BLy = n1->BRy;
+    n2->BRx = p->URx; n2->BRy = p->ULy + halfY;
+
+    n3->ULx = n1->BLx; n3->ULy = n1->BLy;
+    n3->URx = n1->BRx; n3->URy = n1->BRy;
+    n3->BLx = p->BLx; n3->BLy = p->BLy;
+    n3->BRx = n1->BRx; n3->BRy = p->BLy;
+
+    n4->ULx = n3->URx; n4->ULy = n3->URy;
+    n4->URx = n2->BRx; n4->URy = n2->BRy;
+    n4->BLx = n3->BRx; n4->BLy = n3->BRy;
+    n4->BRx = p->BRx; n4->BRy = p->BRy;
+
+    for (int i = 0; i < p->nkeys; i++) {
+        const oo_cand *kp = &c[p->keys[i]];
+        lnode *dst;
+        if ((float)kp->x < (float)n1->URx) dst = ((float)kp->y < (float)n1->BRy) ? n1 : n3;
+        else dst = ((float)kp->y < (float)n1->BRy) ? n2 : n4;
+        dst->keys[dst->nkeys++] = p->keys[i];
+    }
+    for (int q = 0; q < 4; q++)
+        if (ch[q]->nkeys == 1) ch[q]->noMore = 1;
+}
+
+typedef struct { int size; lnode *node; } sizeptr;
+static int sizeptr_cmp(const void *a, const void *b)
+{
+    const sizeptr *x = (const sizeptr *)a, *y = (const sizeptr *)b;
+    if (x->size != y->size) return x->size < y->size ? -1 : 1;
+    if (x->node->addr != y->node->addr) return x->node->addr < y->node->addr ? -1 : 1;
+    return 0;
+}
+
+static int octree_literal(const oo_cand *c, int n, int width, int height, int N, int *out_idx, int cap)
+{
+    const int nIni = (int)roundf((float)width / (float)height);
+    if (nIni < 1) return -2;
+    const float hX = (float)width / nIni;
+    llist L = {0};
+    lnode **ini = (lnode **)malloc(sizeof(lnode *) * nIni);
+    for (int i = 0; i < nIni; i++) {
+        lnode *ni = node_new(n);
+        ni->ULx = (int)(hX * (float)i); ni->ULy = 0;
+        ni->URx = (int)(hX * (float)(i + 1)); ni->URy = 0;
+        ni->BLx = ni->ULx; ni->BLy = height;
+        ni->BRx = ni->URx; ni->BRy = height;
+        list_push_back(&L, ni);
+        ini[i] = ni;
+    }
+    for (int i = 0; i < n; i++) {
+        int r = (int)((float)c[i].x / hX);
+        if (r < 0 || r >= nIni) { free(ini); return -3; }
+        ini[r]->keys[ini[r]->nkeys++] = i;
+    }
+    free(ini);
+    for (lnode *lit = L.head; lit;) {
+        if (lit->nkeys == 1) { lit->noMore = 1; lit = lit->next; }
+        else if (lit->nkeys == 0) lit = list_erase(&L, lit);
+        else lit = lit->next;
+    }
+
+    int bFinish = 0;
+    sizeptr *vSP = (sizeptr *)malloc(sizeof(sizeptr) * (4 * (size_t)n + 16));
+    sizeptr *vPrev = (sizeptr *)malloc(sizeof(sizeptr) * (4 * (size_t)n + 16));
+    int nSP = 0;
+
+    while (!bFinish) {
+        int prevSize = L.size;
+        int nToExpand = 0;
+        nSP = 0;
+        lnode *lit = L.head;
+        while (lit) {
+            if (lit->noMore) { lit = lit->next; continue; }
+            lnode *ch[4];
+            divide_node(lit, c, ch);
+            for (int q = 0; q < 4; q++) {
+                if (ch[q]->nkeys > 0) {
+                    list_push_front(&L, ch[q]);
+                    if (ch[q]->nkeys > 1) {
+                        nToExpand++;
+                        vSP[nSP].size = ch[q]->nkeys; vSP[nSP].node = ch[q]; nSP++;
+                    }
+                } else
+                    node_free(ch[q]);
+            }
+            lit = list_erase(&L, lit);
+        }
+
+        if (L.size >= N || L.size == prevSize) {
+            bFinish = 1;
+        } else if (L.size + nToExpand * 3 > N) {
+            while (!bFinish) {
+                prevSize = L.size;
+                int nPrev = nSP;
+                memcpy(vPrev, vSP, sizeof(sizeptr) * nSP);
+                nSP = 0;
+                qsort(vPrev, nPrev, sizeof(sizeptr), sizeptr_cmp);
+                for (int j = nPrev - 1; j >= 0; j--) {
+                    lnode *ch[4];
+                    divide_node(vPrev[j].node, c, ch);
+                    for (int q = 0; q < 4; q++) {
+                        if (ch[q]->nkeys > 0) {
+                            list_push_front(&L, ch[q]);
+                            if (ch[q]->nkeys > 1) {
+                                vSP[nSP].size = ch[q]->nkeys; vSP[nSP].node = ch[q]; nSP++;
+                            }
+                        } else
+                            node_free(ch[q]);
+                    }
+                    list_erase(&L, vPrev[j].node);
+                    if (L.size >= N) break;
+                }
+                if (L.size >= N || L.size == prevSize) bFinish = 1;
+            }
+        }
+    }
+    free(vSP);
+    free(vPrev);
+
+    int nout = 0;
+    for (lnode *lit = L.head; lit; lit = lit->next) {
+        int best = lit->keys[0];
+        float maxResponse = (float)c[best].response;
+        for (int k = 1; k < lit->nkeys; k++)
+            if ((float)c[lit->keys[k]].response > maxResponse) {
+                best = lit->keys[k];
+                maxResponse = (float)c[best].response;
+            }
+        if (nout < cap) out_idx[nout] = best;
+        nout++;
+    }
+    while (L.head) list_erase(&L, L.head);
+    return nout;
+}
+
+/* ------------------------------------------------------------------------- */
+/* DistributeOctTree -- array formulation (what the GPU kernel implements)    */
+/*                                                                            */
+/* The list is an array in list order; a pass computes every child partition  */
+/* independently and rebuilds the array with the list discipline              */
+/* "children of the parent processed last come first, each as n4,n3,n2,n1,    */
+/* then the surviving old nodes in their old order".  The size-ordered sweep  */
+/* stops at the first index, in (size, creation) descending order, where      */
+/* |L| + inclusive_scan(children-1) >= N.                                     */
+/* ------------------------------------------------------------------------- */
+typedef struct { int x0, x1, y0, y1, cnt; } anode;
+
+static int quadrant_of(const anode *nd, int x, int y)
+{
+    const int hx = (int)ceilf((float)(nd->x1 - nd->x0) / 2);
+    const int hy = (int)ceilf((float)(nd->y1 - nd->y0) / 2);
+    int right = !((float)x < (float)(nd->x0 + hx));
+    int down = !((float)y < (float)(nd->y0 + hy));
+    return right + 2 * down; /* 0:n1 1:n2 2:n3 3:n4 */
+}
+static void child_rect(const anode *p, int q, anode *c)
+{
+    const int hx = (int)ceilf((float)(p->x1 - p->x0) / 2);
+    const int hy = (int)ceilf((float)(p->y1 - p->y0) / 2);
+    c->x0 = (q & 1) ? p->x0 + hx : p->x0;
+    c->x1 = (q & 1) ? p->x1 : p->x0 + hx;
+    c->y0 = (q & 2) ? p->y0 + hy : p->y0;
+    c->y1 = (q & 2) ? p->y1 : p->y0 + hy;
+}
+
+typedef struct { int cnt, cidx, pos; } sortent;
+static int sortent_cmp_desc(const void *a, const void *b)
+{
+    const sortent *x = (const sortent *)a, *y = (const sortent *)b;
+    if (x->cnt != y->cnt) return x->cnt > y->cnt ? -1 : 1;
+    if (x->cidx != y->cidx) return x->cidx > y->cidx ? -1 : 1;
+    return 0;
+}
+
+static int octree_arrays(const oo_cand *c, int n, int width, int height, int N, int *out_idx, int cap)
+{
+    const int nIni = (int)roundf((float)width / (float)height);
+    if (nIni < 1) return -2;
+    const float hX = (float)width / nIni;
+    int maxNodes = imax(N + 4, 4 * nIni + 4) + 4;
+    anode *cur = (anode *)calloc(maxNodes, sizeof(anode)), *nxt = (anode *)calloc(maxNodes, sizeof(anode));
+    int *knode = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int *kq = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    int *cc = (int *)calloc((size_t)maxNodes * 4, sizeof(int));
+    int *childpos = (int *)calloc((size_t)maxNodes * 4, sizeof(int));
+    int *newpos = (int *)calloc(maxNodes, sizeof(int));
+    int *split = (int *)calloc(maxNodes, sizeof(int));
+    int *cidx_cur = (int *)calloc(maxNodes, sizeof(int)); /* creation index among expandable nodes, -1 if not one */
+    int *cidx_nxt = (int *)calloc(maxNodes, sizeof(int));
+    sortent *se = (sortent *)malloc(sizeof(sortent) * maxNodes);
+    int size = 0, result = 0;
+
+    /* roots :492-534 */
+    {
+        int *rcount = (int *)calloc(nIni, sizeof(int));
+        int *rpos = (int *)malloc(sizeof(int) * nIni);
+        for (int i = 0; i < n; i++) {
+            int r = (int)((float)c[i].x / hX);
+            if (r < 0 || r >= nIni) { result = -3; free(rcount); free(rpos); goto done; }
+            kq[i] = r;
+            rcount[r]++;
+        }
+        for (int r = 0; r < nIni; r++) {
+            rpos[r] = -1;
+            if (rcount[r] == 0) continue;
+            rpos[r] = size;
+            cur[size].x0 = (int)(hX * (float)r);
+            cur[size].x1 = (int)(hX * (float)(r + 1));
+            cur[size].y0 = 0;
+            cur[size].y1 = height;
+            cur[size].cnt = rcount[r];
+            size++;
+        }
+        for (int i = 0; i < n; i++) knode[i] = rpos[kq[i]];
+        free(rcount); free(rpos);
+    }
+
+    int phase2 = 0, finish = 0;
+    while (!finish) {
+        int prevSize = size;
+        /* which nodes are split in this step */
+        int nsplit = 0;
+        if (!phase2) {
+            for (int p = 0; p < size; p++) { split[p] = cur[p].cnt > 1; nsplit += split[p]; }
+        }
+        /* child occupancy of every node that might be split */
+        for (int p = 0; p < size; p++) cc[4 * p] = cc[4 * p + 1] = cc[4 * p + 2] = cc[4 * p + 3] = 0;
+        for (int i = 0; i < n; i++) {
+            int p = knode[i];
+            if (phase2 ? cidx_cur[p] >= 0 : split[p]) {
+                kq[i] = quadrant_of(&cur[p], c[i].x, c[i].y);
+                cc[4 * p + kq[i]]++;
+            }
+        }
+        /* processing order of the split parents */
+        int norder = 0;
+        if (!phase2) {
+            for (int p = 0; p < size; p++)
+                if (split[p]) { se[norder].pos = p; se[norder].cnt = cur[p].cnt; se[norder].cidx = norder; norder++; }
+        } else {
+            for (int p = 0; p < size; p++) {
+                split[p] = 0;
+                if (cidx_cur[p] >= 0) { se[norder].pos = p; se[norder].cnt = cur[p].cnt; se[norder].cidx = cidx_cur[p]; norder++; }
+            }
+            qsort(se, norder, sizeof(sortent), sortent_cmp_desc);
+            /* break position: first s with size + sum_{s'<=s} (children-1) >= N */
+            int run = size, cut = norder;
+            for (int s = 0; s < norder; s++) {
+                int p = se[s].pos;
+                int nch = (cc[4 * p] > 0) + (cc[4 * p + 1] > 0) + (cc[4 * p + 2] > 0) + (cc[4 * p + 3] > 0);
+                run += nch - 1;
+                if (run >= N) { cut = s + 1; break; }
+            }
+            norder = cut;
+            for (int s = 0; s < norder; s++) split[se[s].pos] = 1;
+        }
+        /* new list: children of the parent processed last first (n4..n1), ... */
+        int np = 0, ncreated = 0;
+        for (int s = norder - 1; s >= 0; s--) {
+            int p = se[s].pos;
+            for (int q = 3; q >= 0; q--)
+                if (cc[4 * p + q] > 0) {
+                    childpos[4 * p + q] = np;
+                    child_rect(&cur[p], q, &nxt[np]);
+                    nxt[np].cnt = cc[4 * p + q];
+                    np++;
+                }
+        }
+        /* creation order (for the next size sort): processing order, then n1..n4 */
+        for (int k = 0; k < np; k++) cidx_nxt[k] = -1;
+        for (int s = 0; s < norder; s++) {
+            int p = se[s].pos;
+            for (int q = 0; q < 4; q++)
+                if (cc[4 * p + q] > 1) cidx_nxt[childpos[4 * p + q]] = ncreated++;
+        }
+        for (int p = 0; p < size; p++)
+            if (!split[p]) {
+                newpos[p] = np;
+                nxt[np] = cur[p];
+                cidx_nxt[np] = -1; /* old nodes are never revisited by the size-ordered sweep */
+                np++;
+            }
+        if (!phase2) {
+            /* phase 1 revisits every multi-key node, old or new: none are old */
+        }
+        for (int i = 0; i < n; i++) {
+            int p = knode[i];
+            knode[i] = split[p] ? childpos[4 * p + kq[i]] : newpos[p];
+        }
+        { anode *t = cur; cur = nxt; nxt = t; }
+        { int *t = cidx_cur; cidx_cur = cidx_nxt; cidx_nxt = t; }
+        size = np;
+        if (size > maxNodes - 4) { result = -4; goto done; }
+
+        if (size >= N || size == prevSize) finish = 1;
+        else if (!phase2 && size + ncreated * 3 > N) phase2 = 1;
+    }
+
+    /* best key of every node: max response, first in key order on ties (:689-710) */
+    {
+        int *best = (int *)malloc(sizeof(int) * (size > 0 ? size : 1));
+        for (int p = 0; p < size; p++) best[p] = -1;
+        for (int i = 0; i < n; i++) {
+            int p = knode[i];
+            if (best[p] < 0 || c[i].response > c[best[p]].response) best[p] = i;
+        }
+        for (int p = 0; p < size; p++) {
+            if (p < cap) out_idx[p] = best[p];
+        }
+        result = size;
+        free(best);
+    }
+done:
+    free(cur); free(nxt); free(knode); free(kq); free(cc); free(childpos); free(newpos);
+    free(split); free(cidx_cur); free(cidx_nxt); free(se);
+    return result;
+}
+
+int oo_distribute_octree(const oo_cand *cands, int n, int width, int height, int N,
+                         int literal, int *out_idx, int cap)
+{
+    return literal ? octree_literal(cands, n, width, height, N, out_idx, cap)
+                   : octree_arrays(cands, n, width, height, N, out_idx, cap);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Orientation: IC_Angle src/ORBextractor.cc:74-101 + cv::fastAtan2           */
+/* ------------------------------------------------------------------------- */
+void oo_ic_moments(const uint8_t *center, int stride, const int *umax, int *m01_out, int *m10_out)
+{
+    int m_01 = 0, m_10 = 0;
+    for (int u = -OO_HALF_PATCH; u <= OO_HALF_PATCH; ++u) m_10 += u * center[u];
+    for (int v = 1; v <= OO_HALF_PATCH; ++v) {
+        int v_sum = 0;
+        int d = umax[v];
+        for (int u = -d; u <= d; ++u) {
+            int val_plus = center[u + v * stride], val_minus = center[u - v * stride];
+            v_sum += (val_plus - val_minus);
+            m_10 += u * (val_plus + val_minus);
+        }
+        m_01 += v * v_sum;
+    }
+    *m01_out = m_01;
+    *m10_out = m_10;
+}
+
+/* OpenCV 3.4.1 semantics: cv::fastAtan2 (core/src/mathfuncs_core.simd.hpp atan_f32) */
+float oo_fast_atan2(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16; /* (float)DBL_EPSILON */
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + eps);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + eps);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+/* ------------------------------------------------------------------------- */
+/* OpenCV 3.4.1 semantics: GaussianBlur 7x7, sigma 2, 8-bit                   */
+/* separable kernel round(256*g) = [18,34,49,55,49,34,18] (sum 257, not        */
+/* renormalised), exact integer sums, dst = sat_u8((acc + 32768) >> 16).       */
+/* ------------------------------------------------------------------------- */
+static void gauss7_kernel(int k[7])
+{
+    /* getGaussianKernel(7, 2): exp(-x^2/(2 sigma^2)) normalised, then fixed point 8.8 */
+    double g[7], sum = 0;
+    for (int i = 0; i < 7; i++) { double x = i - 3; g[i] = exp(-0.5 * x * x / 4.0); sum += g[i]; }
+    for (int i = 0; i < 7; i++) k[i] = (int)lrint(256.0 * g[i] / sum);
+}
+
+void oo_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *dst, int dstride)
+{
+    int k[7];
+    gauss7_kernel(k);
+    int *rows = (int *)malloc(sizeof(int) * (size_t)w * (h + 6));
+    for (int y = -3; y < h + 3; y++) {
+        const uint8_t *s = src + (ptrdiff_t)y * sstride;
+        int *r = rows + (size_t)(y + 3) * w;
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int t = 0; t < 7; t++) acc += k[t] * s[x + t - 3];
+            r[x] = acc;
+        }
+    }
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int acc = 0;
+            for (int t = 0; t < 7; t++) acc += k[t] * rows[(size_t)(y + t) * w + x];
+            int v = (acc + 32768) >> 16;
+            dst[(size_t)y * dstride + x] = (uint8_t)(v > 255 ? 255 : v);
+        }
+    free(rows);
+}
+
+/* ------------------------------------------------------------------------- */
+/* computeOrbDescriptor src/ORBextractor.cc:103-150                           */
+/* ------------------------------------------------------------------------- */
+void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32])
+{
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float angle = angle_deg * factorPI;
+    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    const int *pat = g_pattern;
+    for (int i = 0; i < 32; ++i, pat += 32) {
+        int val = 0;
+        for (int k = 0; k < 8; k++) {
+            int x0 = pat[4 * k], y0 = pat[4 * k + 1], x1 = pat[4 * k + 2], y1 = pat[4 * k + 3];
+            float r0 = x0 * b + y0 * a, c0 = x0 * a - y0 * b;
+            float r1 = x1 * b + y1 * a, c1 = x1 * a - y1 * b;
+            int t0 = center[cv_round_f(r0) * stride + cv_round_f(c0)];
+            int t1 = center[cv_round_f(r1) * stride + cv_round_f(c1)];
+            val |= (t0 < t1) << k;
+        }
+        desc[i] = (uint8_t)val;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* ORBextractor::operator() src/ORBextractor.cc:1127-1190 and                 */
+/* ComputeKeyPointsOctTree :1028-1125                                         */
+/* ------------------------------------------------------------------------- */
+int oo_extract(oo_extractor *ex, const uint8_t *img, int w, int h, int stride,
+               oo_keypoint *kps, uint8_t *desc, int cap, int literal)
+{
+    const int B = OO_EDGE_THRESHOLD;
+    if (!img || w <= 0 || h <= 0) return 0;
+    if (oo_compute_pyramid(ex, img, w, h, stride) != 0) return -1;
+    int total = 0;
+    for (int level = 0; level < ex->nlevels; level++) {
+        ex->level_counts[level] = 0;
+        const int cols = ex->lw[level], rows = ex->lh[level];
+        const int pitch = cols + 2 * B;
+        const int width = cols - 32, height = rows - 32;
+        if (width < 30 || height < 30) continue; /* reference would divide by zero (nCols/nRows == 0) */
+        int ccap = (width * height) / 4 + 64;
+        oo_cand *cand = (oo_cand *)malloc(sizeof(oo_cand) * ccap);
+        int ncand = oo_detect_level(ex, level, literal, cand, ccap);
+        if (ncand > ccap) { free(cand); return -1; }
+        int ocap = imax(ex->nfeat[level] + 8, 4 * (width / height + 2) + 8);
+        int *sel = (int *)malloc(sizeof(int) * ocap);
+        int nsel = oo_distribute_octree(cand, ncand, width, height, ex->nfeat[level], literal, sel, ocap);
+        if (nsel < 0 || nsel > ocap) { free(cand); free(sel); return -1; }
+        if (total + nsel > cap) { free(cand); free(sel); return -1; }
+
+        const uint8_t *im = ex->plane[level] + (size_t)B * pitch + B;
+        const int scaledPatchSize = (int)(OO_PATCH * ex->scale[level]); /* :1109 */
+        uint8_t *blur = NULL;
+        if (nsel > 0) {
+            blur = (uint8_t *)malloc((size_t)cols * rows);
+            oo_gaussian_blur7(im, cols, rows, pitch, blur, cols);
+        }
+        for (int k = 0; k < nsel; k++) {
+            oo_keypoint *kp = &kps[total + k];
+            kp->x = (float)(cand[sel[k]].x + 16); /* :1115-1118 */
+            kp->y = (float)(cand[sel[k]].y + 16);
+            kp->octave = level;
+            kp->size = (float)scaledPatchSize;
+            kp->response = (float)cand[sel[k]].response;
+            kp->class_id = -1;
+            int cx = cv_round_f(kp->x), cy = cv_round_f(kp->y);
+            int m01, m10;
+            oo_ic_moments(im + (size_t)cy * pitch + cx, pitch, ex->umax, &m01, &m10);
+            kp->angle = oo_fast_atan2((float)m01, (float)m10);
+            oo_orb_descriptor(blur + (size_t)cy * cols + cx, cols, kp->angle, desc + (size_t)(total + k) * 32);
+            if (level != 0) { /* :1179-1186 */
+                float scale = ex->scale[level];
+                kp->x *= scale;
+                kp->y *= scale;
+            }
+        }
+        free(blur);
+        free(cand);
+        free(sel);
+        ex->level_counts[level] = nsel;
+        total += nsel;
+    }
+    return total;
+}
+
+void oo_last_level_counts(const oo_extractor *ex, int *counts)
+{
+    for (int i = 0; i < ex->nlevels; i++) counts[i] = ex->level_counts[i];
+}
+
+/* ------------------------------------------------------------------------- */
+/* Matching                                                                   */
+/* ------------------------------------------------------------------------- */
+/* src/ORBmatcher.cc:1768-1784 (SWAR popcount) */
+int oo_hamming(const uint32_t pa[8], const uint32_t pb[8])
+{
+    int dist = 0;
+    for (int i = 0; i < 8; i++, pa++, pb++) {
+        unsigned int v = *pa ^ *pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101) >> 24;
+    }
+    return dist;
+}
+
+void oo_match_bruteforce(const uint32_t *q, int Q, const uint32_t *t, int T,
+                         int32_t *best_idx, int32_t *best_dist, int32_t *second_dist)
+{
+    for (int i = 0; i < Q; i++) {
+        int bestDist = 256, bestDist2 = 256, bestIdx = -1;
+        for (int j = 0; j < T; j++) {
+            int dist = oo_hamming(q + 8 * (size_t)i, t + 8 * (size_t)j);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = j; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist; second_dist[i] = bestDist2;
+    }
+}
+
+void oo_match_windowed(const uint32_t *q, int Q, const uint32_t *t, int T,
+                       const int32_t *cand_off, const int32_t *cand_idx, const int32_t *t_octave,
+                       int32_t *best_idx, int32_t *best_dist, int32_t *second_dist,
+                       int32_t *best_lvl, int32_t *second_lvl)
+{
+    (void)T;
+    for (int i = 0; i < Q; i++) {
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = cand_off[i]; k < cand_off[i + 1]; k++) {
+            int idx = cand_idx[k];
+            int dist = oo_hamming(q + 8 * (size_t)i, t + 8 * (size_t)idx);
+            int lvl = t_octave ? t_octave[idx] : 0;
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = lvl; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = lvl; bestDist2 = dist;
+            }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist; second_dist[i] = bestDist2;
+        if (best_lvl) best_lvl[i] = bestLevel;
+        if (second_lvl) second_lvl[i] = bestLevel2;
+    }
+}
+
+void oo_hamming_csr(const uint32_t *q, int Q, const uint32_t *t, int T,
+                    const int32_t *cand_off, const int32_t *cand_idx, uint16_t *dist_out)
+{
+    (void)T;
+    for (int i = 0; i < Q; i++)
+        for (int k = cand_off[i]; k < cand_off[i + 1]; k++)
+            dist_out[k] = (uint16_t)oo_hamming(q + 8 * (size_t)i, t + 8 * (size_t)cand_idx[k]);
+}
+
+/* include/Frame.h:217-251 + src/Frame.cc:1306-1375 */
+void oo_stereo_search(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                      const oo_keypoint *kr, const uint32_t *dr, int nr,
+                      const float *scale_factors, int nrows, float minD, float maxD, float minX,
+                      int32_t *best_idx, int32_t *best_dist)
+{
+    /* row table (CSR built in two passes; order inside a row = ascending iR) */
+    int *cnt = (int *)calloc((size_t)nrows + 1, sizeof(int));
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * scale_factors[kr[iR].octave];
+        const int maxr = (int)fminf((float)(nrows - 1), ceilf(kpY + r));
+        const int minr = (int)fmaxf(0.0f, floorf(kpY - r));
+        for (int yi = minr; yi <= maxr; yi++) cnt[yi + 1]++;
+    }
+    for (int y = 0; y < nrows; y++) cnt[y + 1] += cnt[y];
+    int *fill = (int *)malloc(sizeof(int) * ((size_t)nrows + 1));
+    memcpy(fill, cnt, sizeof(int) * ((size_t)nrows + 1));
+    int *rowidx = (int *)malloc(sizeof(int) * (cnt[nrows] > 0 ? cnt[nrows] : 1));
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * scale_factors[kr[iR].octave];
+        const int maxr = (int)fminf((float)(nrows - 1), ceilf(kpY + r));
+        const int minr = (int)fmaxf(0.0f, floorf(kpY - r));
+        for (int yi = minr; yi <= maxr; yi++) rowidx[fill[yi]++] = iR;
+    }
+    for (int iL = 0; iL < nl; iL++) {
+        best_idx[iL] = -1;
+        best_dist[iL] = 100; /* ORBmatcher::TH_HIGH */
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        if (vL < 0 || vL > nrows - 1) continue;
+        int row = (int)vL;
+        if (cnt[row + 1] == cnt[row]) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < minX) continue;
+        int bestDist = 100, bestIdxR = 0;
+        for (int k = cnt[row]; k < cnt[row + 1]; k++) {
+            int iR = rowidx[k];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                int dist = oo_hamming(dl + 8 * (size_t)iL, dr + 8 * (size_t)iR);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        best_idx[iL] = bestIdxR;
+        best_dist[iL] = bestDist;
+    }
+    free(cnt); free(fill); free(rowidx);
+}
+
+typedef struct { int dist, idx; } distidx;
+static int distidx_cmp(const void *a, const void *b)
+{
+    const distidx *x = (const distidx *)a, *y = (const distidx *)b;
+    if (x->dist != y->dist) return x->dist < y->dist ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+/* src/Frame.cc:1380-1419 */
+int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
+                     const int32_t *best_idx, const int32_t *best_dist,
+                     float mbf, float minD, float maxD, float *u_right, float *depth)
+{
+    const int thOrbDist = (100 + 50) / 2;
+    distidx *v = (distidx *)malloc(sizeof(distidx) * (nl > 0 ? nl : 1));
+    int nv = 0, nmatched = 0;
+    for (int iL = 0; iL < nl; iL++) {
+        u_right[iL] = -1.0f;
+        depth[iL] = -1.0f;
+        if (best_idx[iL] < 0) continue;
+        if (best_dist[iL] < thOrbDist) {
+            float bestuR = kr[best_idx[iL]].x;
+            float disparity = kl[iL].x - bestuR;
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = (float)(kl[iL].x - 0.01);
+                }
+                depth[iL] = mbf / disparity;
+                u_right[iL] = bestuR;
+                v[nv].dist = best_dist[iL]; v[nv].idx = iL; nv++;
+            }
+        }
+        nmatched++;
+    }
+    if (nv > 0) {
+        qsort(v, nv, sizeof(distidx), distidx_cmp);
+        const float median = (float)v[nv / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; i--) {
+            if ((float)v[i].dist < thDist) break;
+            u_right[v[i].idx] = -1;
+            depth[v[i].idx] = -1;
+            nmatched--;
+        }
+    }
+    free(v);
+    return nmatched;
+}

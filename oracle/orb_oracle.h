@@ -1,0 +1,146 @@
+/*
+ * orb_oracle.h -- CPU restatement of the GF-ORB-SLAM2 ORB front-end.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the shipped GPU library links, loads or
+ * calls this code; it exists so that tests, the smoke check and the CPU-baseline
+ * leg of the benchmark have something to compare the GPU results against.
+ *
+ * PARITY UNPINNED: the reference holds no golden keypoints / descriptors /
+ * matches for this path (test/test_Stereo.cpp:230-245 asserts nothing), and its
+ * arithmetic lives in OpenCV 3.4.1, which is neither vendored in the reference
+ * nor installed here.  This file therefore restates the published OpenCV 3.4.1
+ * generic (non-IPP) algorithms at the reference's call sites; every OpenCV
+ * semantic choice is in orb_oracle.c under a "OpenCV 3.4.1 semantics" banner.
+ *
+ * Each function cites the reference file:line it follows.
+ */
+#ifndef ORB_ORACLE_H
+#define ORB_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OO_EDGE_THRESHOLD 19   /* src/ORBextractor.cc:72 */
+#define OO_HALF_PATCH 15       /* src/ORBextractor.cc:71 */
+#define OO_PATCH 31            /* src/ORBextractor.cc:70 */
+#define OO_MAX_LEVELS 16
+
+/* layout-identical to cv::KeyPoint (7 x 4 bytes) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oo_keypoint;
+
+/* FAST candidate in the coordinate frame of ComputeKeyPointsOctTree:
+ * relative to (minBorderX, minBorderY) = (16, 16) of the level image. */
+typedef struct {
+    int32_t x, y, response;
+} oo_cand;
+
+typedef struct oo_extractor oo_extractor;
+
+/* ORBextractor::ORBextractor, src/ORBextractor.cc:967-1026 */
+oo_extractor *oo_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void oo_destroy(oo_extractor *ex);
+
+/* tables built by the constructor; arrays of nlevels entries (umax: 16) */
+void oo_get_tables(const oo_extractor *ex, float *scale, float *inv_scale, float *sigma2,
+                   float *inv_sigma2, int *nfeat_per_level, int *umax16);
+const int *oo_pattern(void); /* 256*4 ints */
+
+/* level size for an input w x h: src/ORBextractor.cc:1196-1197 */
+void oo_level_size(const oo_extractor *ex, int w, int h, int level, int *lw, int *lh);
+
+/* ORBextractor::ComputePyramid, src/ORBextractor.cc:1192-1216.
+ * Planes are kept inside the extractor until the next call. */
+int oo_compute_pyramid(oo_extractor *ex, const uint8_t *img, int w, int h, int stride);
+/* bordered plane of a level: pointer to its top-left (border) pixel; the level
+ * image starts at (+19,+19).  *bw,*bh are the bordered sizes; pitch == *bw. */
+const uint8_t *oo_pyramid_plane(const oo_extractor *ex, int level, int *bw, int *bh);
+
+/* cv::resize(INTER_LINEAR, 8UC1) for one plane (used by ComputePyramid) */
+void oo_resize_linear_u8(const uint8_t *src, int sw, int sh, int sstride,
+                         uint8_t *dst, int dw, int dh, int dstride);
+
+/* cv::FAST(img, thr, nonmax=true), TYPE_9_16, on a sub-image (literal OpenCV
+ * algorithm: threshold table, run-length test, cornerScore, 3-row NMS).
+ * out: keypoints (x, y, response) in sub-image coordinates, emission order. */
+int oo_fast9_nms(const uint8_t *img, int w, int h, int stride, int threshold,
+                 oo_cand *out, int cap);
+/* threshold-free FAST score of one pixel by the brute-force arc definition
+ * (independent second derivation, used to cross-check the literal path). */
+int oo_fast_score_bruteforce(const uint8_t *center, int stride);
+
+/* Cell loop of ComputeKeyPointsOctTree, src/ORBextractor.cc:1036-1101, on the
+ * pyramid held by ex.  literal!=0: two cv::FAST calls per cell as written;
+ * literal==0: single score-image formulation (must give the same list). */
+int oo_detect_level(const oo_extractor *ex, int level, int literal, oo_cand *out, int cap);
+
+/* ORBextractor::DistributeOctTree, src/ORBextractor.cc:488-711 (+DivideNode :431-486).
+ * Coordinates of cands are relative to (minX,minY); width=maxX-minX, height=maxY-minY.
+ * Writes the indices (into cands) of the retained keypoints in output order.
+ * The reference breaks ties between equally sized nodes by heap address
+ * (:633); here: among equal sizes the node created LATER is split first.
+ * literal!=0: std::list emulation; literal==0: array passes + sort + scan. */
+int oo_distribute_octree(const oo_cand *cands, int n, int width, int height, int N,
+                         int literal, int *out_idx, int cap);
+
+/* IC_Angle, src/ORBextractor.cc:74-101 (moments) and cv::fastAtan2 */
+void oo_ic_moments(const uint8_t *center, int stride, const int *umax16, int *m01, int *m10);
+float oo_fast_atan2(float y, float x);
+
+/* cv::GaussianBlur(7x7, sigma 2, REFLECT_101) on an 8-bit plane whose 3-pixel
+ * border is already present around [0,w)x[0,h): src/ORBextractor.cc:1169-1170 */
+void oo_gaussian_blur7(const uint8_t *src_origin, int w, int h, int sstride,
+                       uint8_t *dst, int dstride);
+
+/* computeOrbDescriptor, src/ORBextractor.cc:104-150 */
+void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32]);
+
+/* ORBextractor::operator(), src/ORBextractor.cc:1127-1190. Returns the number
+ * of keypoints (<= cap) or -1 if cap is too small. literal selects the literal
+ * or the derived formulations of FAST cells and the quadtree. */
+int oo_extract(oo_extractor *ex, const uint8_t *img, int w, int h, int stride,
+               oo_keypoint *kps, uint8_t *desc, int cap, int literal);
+/* per-level keypoint counts of the last oo_extract call */
+void oo_last_level_counts(const oo_extractor *ex, int *counts);
+
+/* ORBmatcher::DescriptorDistance, src/ORBmatcher.cc:1768-1784 */
+int oo_hamming(const uint32_t a[8], const uint32_t b[8]);
+
+/* Brute force: for each query, the first two candidates in (distance, index)
+ * order -- the result of the reference's sequential best/second scan
+ * (src/ORBmatcher.cc:193-225) over the whole train set. */
+void oo_match_bruteforce(const uint32_t *q, int Q, const uint32_t *t, int T,
+                         int32_t *best_idx, int32_t *best_dist, int32_t *second_dist);
+
+/* Windowed search over CSR candidate lists; literal sequential scan of
+ * src/ORBmatcher.cc:186-225 (no exclusion tests). t_octave may be NULL. */
+void oo_match_windowed(const uint32_t *q, int Q, const uint32_t *t, int T,
+                       const int32_t *cand_off, const int32_t *cand_idx, const int32_t *t_octave,
+                       int32_t *best_idx, int32_t *best_dist, int32_t *second_dist,
+                       int32_t *best_lvl, int32_t *second_lvl);
+
+void oo_hamming_csr(const uint32_t *q, int Q, const uint32_t *t, int T,
+                    const int32_t *cand_off, const int32_t *cand_idx, uint16_t *dist_out);
+
+/* Stereo row-band search: Frame::PrepareStereoCandidates (include/Frame.h:217-251)
+ * + the Hamming scan of Frame::ComputeStereoMatches_Undistorted
+ * (src/Frame.cc:1341-1375).  best_dist starts at TH_HIGH=100, strict '<'.
+ * best_idx = -1 when the row has no candidates / maxU < minX (left kp skipped). */
+void oo_stereo_search(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                      const oo_keypoint *kr, const uint32_t *dr, int nr,
+                      const float *scale_factors, int nrows, float minD, float maxD, float minX,
+                      int32_t *best_idx, int32_t *best_dist);
+/* Disparity/depth + median cut: src/Frame.cc:1380-1419 (offline variant). */
+int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
+                     const int32_t *best_idx, const int32_t *best_dist,
+                     float mbf, float minD, float maxD, float *u_right, float *depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

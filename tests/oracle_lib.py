@@ -1,0 +1,265 @@
+"""ctypes binding of the CPU oracle (oracle/liborb_oracle.so).
+
+Test infrastructure: only tests, the smoke check and the CPU-baseline leg of
+the benchmark may import this module; the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+CAND_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("response", "<i4")])
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_u32p = C.POINTER(C.c_uint32)
+_f32p = C.POINTER(C.c_float)
+
+
+def build(native=False):
+    """Compile the oracle with its Makefile if the library is missing."""
+    name = "liborb_oracle_native.so" if native else "liborb_oracle.so"
+    path = os.path.join(ORACLE_DIR, name)
+    src = os.path.join(ORACLE_DIR, "orb_oracle.c")
+    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, name])
+    return path
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Oracle:
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, native=False):
+        self.lib = lib = C.CDLL(build(native))
+        lib.oo_create.restype = C.c_void_p
+        lib.oo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
+        lib.oo_destroy.argtypes = [C.c_void_p]
+        lib.oo_get_tables.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, _f32p, _i32p, _i32p]
+        lib.oo_pattern.restype = _i32p
+        lib.oo_level_size.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _i32p, _i32p]
+        lib.oo_compute_pyramid.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int]
+        lib.oo_pyramid_plane.restype = _u8p
+        lib.oo_pyramid_plane.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p]
+        lib.oo_resize_linear_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int, C.c_int]
+        lib.oo_fast9_nms.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.oo_fast_score_bruteforce.argtypes = [C.c_void_p, C.c_int]
+        lib.oo_detect_level.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.oo_distribute_octree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p, C.c_int]
+        lib.oo_ic_moments.argtypes = [C.c_void_p, C.c_int, _i32p, _i32p, _i32p]
+        lib.oo_fast_atan2.restype = C.c_float
+        lib.oo_fast_atan2.argtypes = [C.c_float, C.c_float]
+        lib.oo_gaussian_blur7.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]
+        lib.oo_orb_descriptor.argtypes = [C.c_void_p, C.c_int, C.c_float, _u8p]
+        lib.oo_extract.argtypes = [C.c_void_p, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, _u8p, C.c_int, C.c_int]
+        lib.oo_last_level_counts.argtypes = [C.c_void_p, _i32p]
+        lib.oo_hamming.argtypes = [_u32p, _u32p]
+        lib.oo_match_bruteforce.argtypes = [_u32p, C.c_int, _u32p, C.c_int, _i32p, _i32p, _i32p]
+        lib.oo_match_windowed.argtypes = [_u32p, C.c_int, _u32p, C.c_int, _i32p, _i32p, _i32p,
+                                          _i32p, _i32p, _i32p, _i32p, _i32p]
+        lib.oo_hamming_csr.argtypes = [_u32p, C.c_int, _u32p, C.c_int, _i32p, _i32p, C.POINTER(C.c_uint16)]
+        lib.oo_stereo_search.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int, _f32p,
+                                         C.c_int, C.c_float, C.c_float, C.c_float, _i32p, _i32p]
+        lib.oo_stereo_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _i32p, _i32p,
+                                         C.c_float, C.c_float, C.c_float, _f32p, _f32p]
+        self.nlevels = nlevels
+        self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
+        if not self.h:
+            raise ValueError("oo_create failed")
+        self._img_shape = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.oo_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- tables -----------------------------------------------------------
+    def tables(self):
+        n = self.nlevels
+        sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+        nf = np.zeros(n, np.int32)
+        um = np.zeros(16, np.int32)
+        self.lib.oo_get_tables(self.h, _ptr(sc, _f32p), _ptr(isc, _f32p), _ptr(s2, _f32p), _ptr(is2, _f32p),
+                               _ptr(nf, _i32p), _ptr(um, _i32p))
+        return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, nfeat=nf, umax=um)
+
+    def pattern(self):
+        return np.ctypeslib.as_array(self.lib.oo_pattern(), shape=(256, 4)).copy()
+
+    def level_size(self, w, h, level):
+        lw, lh = C.c_int32(), C.c_int32()
+        self.lib.oo_level_size(self.h, w, h, level, C.byref(lw), C.byref(lh))
+        return lw.value, lh.value
+
+    # ---- pyramid ----------------------------------------------------------
+    def compute_pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        rc = self.lib.oo_compute_pyramid(self.h, _ptr(img, _u8p), w, h, w)
+        if rc != 0:
+            raise ValueError("oo_compute_pyramid failed")
+        self._img_shape = (h, w)
+
+    def pyramid_plane(self, level):
+        """bordered plane (border 19) of a level as a numpy copy"""
+        bw, bh = C.c_int32(), C.c_int32()
+        p = self.lib.oo_pyramid_plane(self.h, level, C.byref(bw), C.byref(bh))
+        return np.ctypeslib.as_array(p, shape=(bh.value, bw.value)).copy()
+
+    def resize(self, src, dw, dh):
+        src = np.ascontiguousarray(src, np.uint8)
+        dst = np.zeros((dh, dw), np.uint8)
+        self.lib.oo_resize_linear_u8(_ptr(src, _u8p), src.shape[1], src.shape[0], src.shape[1],
+                                     _ptr(dst, _u8p), dw, dh, dw)
+        return dst
+
+    # ---- FAST ---------------------------------------------------------------
+    def fast9_nms(self, img, threshold):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(max(w * h, 1), CAND_DTYPE)
+        n = self.lib.oo_fast9_nms(_ptr(img, _u8p), w, h, w, threshold, out.ctypes.data, out.size)
+        return out[:n].copy()
+
+    def fast_score(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        return self.lib.oo_fast_score_bruteforce(img.ctypes.data + y * img.shape[1] + x, img.shape[1])
+
+    def detect_level(self, level, literal):
+        h, w = self._img_shape
+        lw, lh = self.level_size(w, h, level)
+        cap = max((lw * lh) // 4 + 64, 64)
+        out = np.zeros(cap, CAND_DTYPE)
+        n = self.lib.oo_detect_level(self.h, level, int(literal), out.ctypes.data, cap)
+        assert 0 <= n <= cap
+        return out[:n].copy()
+
+    def distribute_octree(self, cands, width, height, N, literal):
+        cands = np.ascontiguousarray(cands, CAND_DTYPE)
+        cap = max(N + 16, 4 * (width // max(height, 1) + 2) + 16)
+        out = np.zeros(cap, np.int32)
+        n = self.lib.oo_distribute_octree(cands.ctypes.data, len(cands), width, height, N, int(literal),
+                                          _ptr(out, _i32p), cap)
+        if n < 0:
+            raise ValueError("oo_distribute_octree error %d" % n)
+        assert n <= cap
+        return out[:n].copy()
+
+    # ---- orientation / blur / descriptor ------------------------------------
+    def ic_moments(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8)
+        um = self.tables()["umax"]
+        m01, m10 = C.c_int32(), C.c_int32()
+        self.lib.oo_ic_moments(img.ctypes.data + y * img.shape[1] + x, img.shape[1], _ptr(um, _i32p),
+                               C.byref(m01), C.byref(m10))
+        return m01.value, m10.value
+
+    def fast_atan2(self, y, x):
+        return self.lib.oo_fast_atan2(y, x)
+
+    def blur_bordered(self, plane, border):
+        """blur the interior of a bordered plane (border >= 3 on every side)"""
+        plane = np.ascontiguousarray(plane, np.uint8)
+        bh, bw = plane.shape
+        w, h = bw - 2 * border, bh - 2 * border
+        dst = np.zeros((h, w), np.uint8)
+        self.lib.oo_gaussian_blur7(plane.ctypes.data + border * bw + border, w, h, bw, _ptr(dst, _u8p), w)
+        return dst
+
+    def descriptor(self, img, x, y, angle_deg):
+        img = np.ascontiguousarray(img, np.uint8)
+        d = np.zeros(32, np.uint8)
+        self.lib.oo_orb_descriptor(img.ctypes.data + y * img.shape[1] + x, img.shape[1], angle_deg, _ptr(d, _u8p))
+        return d
+
+    # ---- full extraction ------------------------------------------------------
+    def extract(self, img, literal=False, cap=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        if cap is None:
+            cap = int(self.tables()["nfeat"].sum()) + 64 * self.nlevels
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = self.lib.oo_extract(self.h, _ptr(img, _u8p), w, h, w, kps.ctypes.data, _ptr(desc, _u8p), cap, int(literal))
+        if n < 0:
+            raise ValueError("oo_extract failed (%d)" % n)
+        self._img_shape = (h, w)
+        return kps[:n].copy(), desc[:n].copy()
+
+    def last_level_counts(self):
+        c = np.zeros(self.nlevels, np.int32)
+        self.lib.oo_last_level_counts(self.h, _ptr(c, _i32p))
+        return c
+
+    # ---- matching ---------------------------------------------------------------
+    def hamming(self, a, b):
+        a = np.ascontiguousarray(a).view(np.uint32)
+        b = np.ascontiguousarray(b).view(np.uint32)
+        return self.lib.oo_hamming(_ptr(a, _u32p), _ptr(b, _u32p))
+
+    def match_bruteforce(self, q, t):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        Q, T = len(q), len(t)
+        bi, bd, sd = (np.zeros(max(Q, 1), np.int32) for _ in range(3))
+        self.lib.oo_match_bruteforce(_ptr(q.view(np.uint32), _u32p), Q, _ptr(t.view(np.uint32), _u32p), T,
+                                     _ptr(bi, _i32p), _ptr(bd, _i32p), _ptr(sd, _i32p))
+        return bi[:Q], bd[:Q], sd[:Q]
+
+    def match_windowed(self, q, t, cand_off, cand_idx, t_octave=None):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        cand_off = np.ascontiguousarray(cand_off, np.int32)
+        cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        Q = len(q)
+        outs = [np.zeros(max(Q, 1), np.int32) for _ in range(5)]
+        toct = None if t_octave is None else np.ascontiguousarray(t_octave, np.int32)
+        self.lib.oo_match_windowed(_ptr(q.view(np.uint32), _u32p), Q, _ptr(t.view(np.uint32), _u32p), len(t),
+                                   _ptr(cand_off, _i32p), _ptr(cand_idx, _i32p),
+                                   None if toct is None else _ptr(toct, _i32p),
+                                   *[_ptr(o, _i32p) for o in outs])
+        return tuple(o[:Q] for o in outs)
+
+    def hamming_csr(self, q, t, cand_off, cand_idx):
+        q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+        cand_off = np.ascontiguousarray(cand_off, np.int32)
+        cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        out = np.zeros(max(len(cand_idx), 1), np.uint16)
+        self.lib.oo_hamming_csr(_ptr(q.view(np.uint32), _u32p), len(q), _ptr(t.view(np.uint32), _u32p), len(t),
+                                _ptr(cand_off, _i32p), _ptr(cand_idx, _i32p), _ptr(out, C.POINTER(C.c_uint16)))
+        return out[:len(cand_idx)]
+
+    def stereo_search(self, kl, dl, kr, dr, scale_factors, nrows, minD, maxD, minX=0.0):
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        bi = np.zeros(max(len(kl), 1), np.int32)
+        bd = np.zeros(max(len(kl), 1), np.int32)
+        self.lib.oo_stereo_search(kl.ctypes.data, _ptr(dl.view(np.uint32), _u32p), len(kl),
+                                  kr.ctypes.data, _ptr(dr.view(np.uint32), _u32p), len(kr),
+                                  _ptr(sf, _f32p), nrows, minD, maxD, minX, _ptr(bi, _i32p), _ptr(bd, _i32p))
+        return bi[:len(kl)], bd[:len(kl)]
+
+    def stereo_finish(self, kl, kr, best_idx, best_dist, mbf, minD, maxD):
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        bi = np.ascontiguousarray(best_idx, np.int32)
+        bd = np.ascontiguousarray(best_dist, np.int32)
+        ur = np.zeros(max(len(kl), 1), np.float32)
+        dp = np.zeros(max(len(kl), 1), np.float32)
+        n = self.lib.oo_stereo_finish(kl.ctypes.data, len(kl), kr.ctypes.data, _ptr(bi, _i32p), _ptr(bd, _i32p),
+                                      mbf, minD, maxD, _ptr(ur, _f32p), _ptr(dp, _f32p))
+        return n, ur[:len(kl)], dp[:len(kl)]

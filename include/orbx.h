@@ -1,0 +1,183 @@
+/*
+ * orbx.h -- C ABI of liborbx: the MI355X (gfx950) ORB front-end.
+ *
+ * The reference (GF-ORB-SLAM2) has no FFI layer: the boundary of this hot path
+ * is the C++ class interface ORB_SLAM2::ORBextractor (include/ORBextractor.h:71-176)
+ * and the static ORBmatcher::DescriptorDistance (include/ORBmatcher.h:48) plus the
+ * best / second-best scans written around it.  Every entry point below names
+ * the reference interface it replaces.  A header-only C++ adapter with the
+ * reference's class shape on top of this ABI is in include/orbx_adapter.hpp.
+ *
+ * Conventions: every function returns 0 (ORBX_OK) or a negative error code and
+ * never throws; all memory named in a signature is owned by the caller; a
+ * context may be used by one thread at a time, distinct contexts concurrently
+ * (the reference calls the left and right extractor from two threads,
+ * src/Frame.cc:84-87).  There is no CPU path: without a usable gfx950 device
+ * orbx_create fails.
+ */
+#ifndef ORBX_H
+#define ORBX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbx_ctx orbx_ctx;
+
+/* layout-identical to cv::KeyPoint (7 x 4 bytes): pt.x, pt.y, size, angle,
+ * response, octave, class_id -- what operator() fills (src/ORBextractor.cc:1109-1119,
+ * :1123-1124, :1179-1186). */
+typedef struct orbx_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orbx_keypoint;
+
+enum {
+    ORBX_OK = 0,
+    ORBX_ERR_INVALID = -1,     /* bad argument */
+    ORBX_ERR_NO_DEVICE = -2,   /* no usable HIP device / not gfx950 */
+    ORBX_ERR_HIP = -3,         /* a HIP runtime call failed (see orbx_last_error) */
+    ORBX_ERR_CAPACITY = -4,    /* an output buffer is too small */
+    ORBX_ERR_UNSUPPORTED = -5, /* geometry outside what the kernels support */
+    ORBX_ERR_STATE = -6        /* call order violated (e.g. no pyramid yet) */
+};
+
+const char *orbx_version(void);
+
+/* ORBextractor::ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)
+ * include/ORBextractor.h:80-81, src/ORBextractor.cc:967-1026. device >= 0. */
+int orbx_create(orbx_ctx **out, int nfeatures, float scaleFactor, int nlevels,
+                int iniThFAST, int minThFAST, int device);
+/* ~ORBextractor, include/ORBextractor.h:83 */
+void orbx_destroy(orbx_ctx *ctx);
+/* text of the last error on this context ("" if none); never NULL */
+const char *orbx_last_error(const orbx_ctx *ctx);
+/* Run all work of this context on the caller's hipStream_t (NULL: the
+ * context's own stream).  No counterpart in the reference. */
+int orbx_set_stream(orbx_ctx *ctx, void *hip_stream);
+
+/* GetLevels / GetScaleFactor / GetInitThres / GetMinThres, include/ORBextractor.h:92-110 */
+int orbx_get_params(const orbx_ctx *ctx, int *nfeatures, float *scaleFactor, int *nlevels,
+                    int *iniThFAST, int *minThFAST);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (include/ORBextractor.h:112-130) and
+ * mnFeaturesPerLevel; each array has nlevels entries, NULL to skip. */
+int orbx_get_tables(const orbx_ctx *ctx, float *scale, float *inv_scale, float *sigma2,
+                    float *inv_sigma2, int32_t *nfeat_per_level);
+/* Upper bound of keypoints one w x h frame can yield (sum over levels of
+ * max(N_level + 2, 4 * nIni), cf. src/ORBextractor.cc:618-622,679-680). */
+int orbx_max_keypoints(orbx_ctx *ctx, int w, int h, int *max_kps);
+/* Size of pyramid level `level` for a w x h input (src/ORBextractor.cc:1196-1197). */
+int orbx_level_size(const orbx_ctx *ctx, int w, int h, int level, int *lw, int *lh);
+
+/* ORBextractor::operator()(image, mask, keypoints, descriptors),
+ * include/ORBextractor.h:88-90, src/ORBextractor.cc:1127-1190; the mask is
+ * ignored there and has no parameter here.  img: 8-bit gray, `stride` bytes
+ * per row, host memory.  kps[cap], desc[cap*32].  *n_out = number of keypoints;
+ * ORBX_ERR_CAPACITY (with *n_out set) if cap is too small.  An empty image
+ * (img == NULL or w,h <= 0) returns ORBX_OK with *n_out = 0 (:1130-1131). */
+int orbx_extract(orbx_ctx *ctx, const uint8_t *img, int w, int h, int stride,
+                 orbx_keypoint *kps, uint8_t *desc, int cap, int *n_out);
+
+/* The same over nframes independent frames of one size in one launch
+ * sequence.  Host buffers: kps[nframes*cap], desc[nframes*cap*32], n_out[nframes]. */
+int orbx_extract_batch(orbx_ctx *ctx, const uint8_t *const *imgs, int nframes, int w, int h, int stride,
+                       orbx_keypoint *kps, uint8_t *desc, int cap_per_frame, int32_t *n_out);
+
+/* Hot entry: everything resident in device memory, asynchronous on the
+ * context's stream, no host synchronisation.  d_imgs: nframes frames,
+ * `stride` bytes per row, `frame_stride` bytes between frames.  A frame that
+ * yields more than cap_per_frame keypoints stores the first cap_per_frame and
+ * reports the full count in d_n_out. */
+int orbx_extract_batch_device(orbx_ctx *ctx, const uint8_t *d_imgs, int nframes, int w, int h,
+                              int stride, size_t frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc,
+                              int cap_per_frame, int32_t *d_n_out);
+
+/* ORBextractor::ComputePyramid(cv::Mat image), include/ORBextractor.h:143,
+ * src/ORBextractor.cc:1192-1216 (public: it is called on its own by the
+ * detection-I/O path, src/Frame.cc:187-190).  Host image, one frame. */
+int orbx_compute_pyramid(orbx_ctx *ctx, const uint8_t *img, int w, int h, int stride);
+
+/* mvImagePyramid[level] (include/ORBextractor.h:138): host-readable view of
+ * the un-blurred level image of frame `frame` of the last extract /
+ * compute_pyramid call.  *data points at pixel (0,0) of the level; at least
+ * 19 valid REFLECT_101 border pixels surround it at the same stride.  Valid
+ * until the next call on this context. */
+int orbx_pyramid_level(orbx_ctx *ctx, int frame, int level, const uint8_t **data,
+                       int *w, int *h, int *stride);
+
+/* --- inspection of intermediate stages (used by the parity tests) -------- */
+/* FAST candidates of one level after the per-cell threshold fallback
+ * (src/ORBextractor.cc:1052-1101), in the reference's append order;
+ * xyr = cap triples (x, y, response), coordinates relative to (16,16). */
+int orbx_debug_candidates(orbx_ctx *ctx, int frame, int level, int32_t *xyr, int cap, int *n);
+/* keypoints retained per level by the quadtree (src/ORBextractor.cc:1106-1107) */
+int orbx_debug_level_counts(orbx_ctx *ctx, int frame, int32_t *counts);
+/* blurred level image (src/ORBextractor.cc:1169-1170), w*h bytes, tightly packed */
+int orbx_debug_blurred_level(orbx_ctx *ctx, int frame, int level, uint8_t *out, size_t out_size);
+/* Per-stage GPU time of the batch calls since the last reset, measured with
+ * HIP events on the context's stream. names: static strings; returns the
+ * number of stages written (<= cap). Synchronises the stream. */
+int orbx_stage_times(orbx_ctx *ctx, const char **names, float *total_ms, int32_t *launches, int cap);
+int orbx_reset_stage_times(orbx_ctx *ctx);
+
+/* --- matching -------------------------------------------------------------- */
+/* ORBmatcher::DescriptorDistance, include/ORBmatcher.h:48,
+ * src/ORBmatcher.cc:1768-1784: 256-bit Hamming distance of one pair, on the
+ * calling thread (pure function, as in the reference). */
+int orbx_hamming(const uint32_t a[8], const uint32_t b[8]);
+
+/* Brute-force search: for every query the first two train descriptors in
+ * (distance, index) order, i.e. the outcome of the reference's sequential
+ * "dist < bestDist / else if dist < bestDist2" scan (src/ORBmatcher.cc:186-225)
+ * over the whole train set.  T == 0: best_idx = -1, distances 256.
+ * Host buffers, synchronous. */
+int orbx_match_bruteforce(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_t *t, int T,
+                          int32_t *best_idx, int32_t *best_dist, int32_t *second_dist);
+/* Device-resident, asynchronous, batched: batch b uses queries
+ * d_q + b*q_stride*8 (count d_nq[b] <= q_stride, or Q if d_nq == NULL) against
+ * train descriptors d_t + b*t_stride*8 (count d_nt[b] or T; t_stride = 0
+ * shares one train set).  Outputs are [nbatch][q_stride]. */
+int orbx_match_bruteforce_device(orbx_ctx *ctx, const uint32_t *d_q, int Q, int q_stride, const int32_t *d_nq,
+                                 const uint32_t *d_t, int T, int t_stride, const int32_t *d_nt, int nbatch,
+                                 int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist);
+
+/* Windowed search over per-query candidate lists in CSR form (cand_off[Q+1],
+ * cand_idx[]): best / second-best distance, index and octave exactly as the
+ * scan at src/ORBmatcher.cc:186-225 leaves them (first candidate in list order
+ * wins ties).  t_octave, best_lvl, second_lvl may be NULL. Host buffers. */
+int orbx_match_windowed(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_t *t, int T,
+                        const int32_t *cand_off, const int32_t *cand_idx, const int32_t *t_octave,
+                        int32_t *best_idx, int32_t *best_dist, int32_t *second_dist,
+                        int32_t *best_lvl, int32_t *second_lvl);
+/* All candidate distances, so that a caller can replay the reference's
+ * sequential exclusions (e.g. src/ORBmatcher.cc:197-199, :559-560) on the host. */
+int orbx_hamming_csr(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_t *t, int T,
+                     const int32_t *cand_off, const int32_t *cand_idx, uint16_t *dist_out);
+
+/* Stereo row-band search + disparity + median cut:
+ * Frame::PrepareStereoCandidates (include/Frame.h:217-251) and
+ * Frame::ComputeStereoMatches_Undistorted(false) (src/Frame.cc:1262-1422)
+ * without map-point priors.  Host buffers, one pair.
+ * best_idx[i] = -1 if left keypoint i was skipped before the scan.
+ * u_right/depth: -1 where there is no match.  *nmatched as returned there. */
+int orbx_stereo_match(orbx_ctx *ctx, const orbx_keypoint *kl, const uint32_t *dl, int nl,
+                      const orbx_keypoint *kr, const uint32_t *dr, int nr,
+                      int nrows, float mbf, float mb, float min_x,
+                      int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth, int *nmatched);
+/* Device-resident, asynchronous, batched over stereo pairs: pair b reads
+ * d_kl + b*stride (d_nl[b] keypoints), d_dl + b*stride*8, likewise right.
+ * Outputs [nbatch][stride]; d_nmatched[nbatch]. */
+int orbx_stereo_match_device(orbx_ctx *ctx, const orbx_keypoint *d_kl, const uint32_t *d_dl, const int32_t *d_nl,
+                             const orbx_keypoint *d_kr, const uint32_t *d_dr, const int32_t *d_nr,
+                             int nbatch, int stride, int nrows, float mbf, float mb, float min_x,
+                             int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
+                             int32_t *d_nmatched);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBX_H */

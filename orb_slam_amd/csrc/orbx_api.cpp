@@ -1,0 +1,727 @@
+// orbx_api.cpp -- C ABI of liborbx (see include/orbx.h): context, device memory,
+// launch sequences.  Host code only; every result is computed by the kernels in
+// orbx_kernels.hip / orbx_match.hip.  There is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/orbx.h"
+#include "orbx_common.hpp"
+#include "orbx_kernels.hpp"
+#include "orbx_tables.hpp"
+
+using namespace orbx;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t ensure(size_t need)
+    {
+        if (need <= bytes) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; bytes = 0; if (e != hipSuccess) return e; }
+        // grow geometrically so that slowly growing batches do not reallocate every call
+        size_t want = need + need / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        bytes = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+enum Stage { ST_PYR0 = 0, ST_RESIZE, ST_BLUR, ST_FAST, ST_QUADTREE, ST_DESC, ST_COUNT };
+const char* kStageNames[ST_COUNT] = {"pyr_level0", "pyr_resize", "blur", "fast_cells", "quadtree", "orient_desc"};
+constexpr int kEventSets = 64;
+
+struct EventSet {
+    hipEvent_t ev[ST_COUNT + 1];
+    bool pending = false;
+};
+
+} // namespace
+
+struct orbx_ctx {
+    Params p;
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    std::string err;
+
+    // geometry of the current frame size
+    int gw = 0, gh = 0;
+    FrameGeom g;
+    TileMap tm;
+    DevBuf xtab, ytab;
+
+    // per-batch working set
+    int cap_frames = 0;
+    DevBuf pyr, blur, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand;
+
+    // staging for the host-buffer entry points
+    DevBuf in, out_kps, out_desc, out_n;
+    // scratch for matching
+    DevBuf partial, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
+
+    int last_nframes = 0;
+    bool have_pyramid = false, have_features = false;
+    std::vector<uint8_t> h_pyr;
+    int h_pyr_frame = -1;
+
+    // stage timing
+    EventSet evs[kEventSets];
+    bool events_ok = false;
+    int ev_next = 0;
+    double stage_ms[ST_COUNT] = {0};
+    int stage_launches[ST_COUNT] = {0};
+};
+
+namespace {
+
+int fail(orbx_ctx* c, int code, const char* what)
+{
+    if (c) c->err = what;
+    return code;
+}
+
+int fail_hip(orbx_ctx* c, const char* what, hipError_t e)
+{
+    if (c) {
+        c->err = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    return ORBX_ERR_HIP;
+}
+
+#define HIPCHECK(c, x)                                              \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) return fail_hip((c), #x, e_);         \
+    } while (0)
+
+void harvest(orbx_ctx* c, EventSet& es)
+{
+    if (!es.pending) return;
+    (void)hipEventSynchronize(es.ev[ST_COUNT]);
+    for (int s = 0; s < ST_COUNT; s++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, es.ev[s], es.ev[s + 1]) == hipSuccess) {
+            c->stage_ms[s] += ms;
+            c->stage_launches[s] += 1;
+        }
+    }
+    es.pending = false;
+}
+
+int ensure_geometry(orbx_ctx* c, int w, int h)
+{
+    if (c->gw == w && c->gh == h) return ORBX_OK;
+    FrameGeom g;
+    std::vector<XTab> xt;
+    std::vector<YTab> yt;
+    const char* msg = "";
+    int rc = build_geometry(c->p, w, h, g, xt, yt, &msg);
+    if (rc != ORBX_OK) return fail(c, rc, msg);
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].key_cap >= (1u << 21)) return fail(c, ORBX_ERR_UNSUPPORTED, "a level has more than 2^21 candidate slots");
+    if (quadtree_prepare(g.max_nodes) != 0) return fail(c, ORBX_ERR_UNSUPPORTED, "quadtree needs more LDS than one CU has");
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // old tables may still be in use
+    HIPCHECK(c, c->xtab.ensure(xt.size() * sizeof(XTab)));
+    HIPCHECK(c, c->ytab.ensure(yt.size() * sizeof(YTab)));
+    HIPCHECK(c, hipMemcpyAsync(c->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // xt/yt are stack-owned
+    c->g = g;
+    make_blur_tilemap(c->g, c->tm);
+    c->gw = w;
+    c->gh = h;
+    c->cap_frames = 0;   // per-frame sizes changed
+    c->have_pyramid = c->have_features = false;
+    return ORBX_OK;
+}
+
+int ensure_frames(orbx_ctx* c, int nframes)
+{
+    if (nframes <= c->cap_frames) return ORBX_OK;
+    const FrameGeom& g = c->g;
+    const size_t n = (size_t)nframes;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, c->pyr.ensure(n * g.pyr_frame_bytes + 256));
+    HIPCHECK(c, c->blur.ensure(n * g.pyr_frame_bytes + 256));
+    HIPCHECK(c, c->cell_cand.ensure((n * g.cand_per_frame + 64) * 4));
+    HIPCHECK(c, c->cell_count.ensure((n * g.ncells + 64) * 4));
+    HIPCHECK(c, c->cell_off.ensure((n * g.ncells + 64) * 4));
+    HIPCHECK(c, c->key_xy.ensure((n * g.keys_per_frame + 64) * 4));
+    HIPCHECK(c, c->key_resp.ensure(n * g.keys_per_frame + 64));
+    HIPCHECK(c, c->key_node.ensure((n * g.keys_per_frame + 64) * 2));
+    HIPCHECK(c, c->kp_stage.ensure((n * (size_t)g.kp_per_frame + 64) * 8));
+    HIPCHECK(c, c->level_count.ensure(n * kMaxLevels * 4));
+    HIPCHECK(c, c->level_ncand.ensure(n * kMaxLevels * 4));
+    // the blurred planes are only written inside the level images; give the rest a defined value once
+    HIPCHECK(c, hipMemsetAsync(c->blur.p, 0, c->blur.bytes, c->stream));
+    c->cap_frames = nframes;
+    return ORBX_OK;
+}
+
+// the launch sequence; everything asynchronous on c->stream
+int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int stride, size_t frame_stride,
+              orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out, bool pyramid_only)
+{
+    int rc = ensure_geometry(c, w, h);
+    if (rc != ORBX_OK) return rc;
+    rc = ensure_frames(c, nframes);
+    if (rc != ORBX_OK) return rc;
+    const FrameGeom& g = c->g;
+    hipStream_t s = c->stream;
+    EventSet* es = nullptr;
+    if (c->events_ok && !pyramid_only) {
+        es = &c->evs[c->ev_next];
+        c->ev_next = (c->ev_next + 1) % kEventSets;
+        harvest(c, *es);
+    }
+    auto mark = [&](int i) { if (es) (void)hipEventRecord(es->ev[i], s); };
+
+    mark(ST_PYR0);
+    launch_pyr_level0(d_imgs, stride, frame_stride, c->pyr.as<uint8_t>(), g, nframes, s);
+    mark(ST_RESIZE);
+    for (int l = 1; l < g.nlevels; l++)
+        launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
+    c->last_nframes = nframes;
+    c->have_pyramid = true;
+    c->have_features = false;
+    c->h_pyr_frame = -1;
+    if (pyramid_only) {
+        HIPCHECK(c, hipGetLastError());
+        return ORBX_OK;
+    }
+    mark(ST_BLUR);
+    launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, s);
+    mark(ST_FAST);
+    launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    mark(ST_QUADTREE);
+    launch_quadtree(g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), c->cell_off.as<int>(),
+                    c->key_xy.as<uint32_t>(), c->key_resp.as<uint8_t>(), c->key_node.as<uint16_t>(), c->kp_stage.p,
+                    c->level_count.as<int>(), c->level_ncand.as<int>(), nframes, s);
+    mark(ST_DESC);
+    launch_orient_desc(g, c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), c->kp_stage.p, c->level_count.as<int>(),
+                       d_kps, d_desc, cap, d_n_out, nframes, s);
+    mark(ST_COUNT);
+    if (es) es->pending = true;
+    HIPCHECK(c, hipGetLastError());
+    c->have_features = true;
+    return ORBX_OK;
+}
+
+int check_frame_args(orbx_ctx* c, int nframes, int w, int h, int stride)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (nframes < 1 || nframes > 65535) return fail(c, ORBX_ERR_INVALID, "nframes must be in [1, 65535]");
+    if (w < 1 || h < 1 || stride < w) return fail(c, ORBX_ERR_INVALID, "bad image size or stride");
+    return ORBX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* orbx_version(void) { return "orbx 0.1 (gfx950)"; }
+
+int orbx_create(orbx_ctx** out, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device)
+{
+    if (!out) return ORBX_ERR_INVALID;
+    *out = nullptr;
+    if (device < 0) return ORBX_ERR_NO_DEVICE;   // there is no CPU path
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev) return ORBX_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ORBX_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ORBX_ERR_NO_DEVICE;   // code objects are gfx950 only
+    orbx_ctx* c = new (std::nothrow) orbx_ctx();
+    if (!c) return ORBX_ERR_INVALID;
+    if (!build_params(c->p, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)) {
+        delete c;
+        return ORBX_ERR_INVALID;
+    }
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ORBX_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    int taps[7];
+    gauss7_taps(taps);
+    if (upload_constant_tables(c->p.patch_du, c->p.patch_dv, taps, c->stream) != 0) {
+        (void)hipStreamDestroy(c->own_stream);
+        delete c;
+        return ORBX_ERR_HIP;
+    }
+    c->events_ok = true;
+    for (int i = 0; i < kEventSets && c->events_ok; i++)
+        for (int j = 0; j <= ST_COUNT; j++)
+            if (hipEventCreate(&c->evs[i].ev[j]) != hipSuccess) { c->events_ok = false; break; }
+    *out = c;
+    return ORBX_OK;
+}
+
+void orbx_destroy(orbx_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
+                      &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
+                      &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
+                      &c->m7, &c->m8, &c->m9};
+    for (DevBuf* b : bufs) b->release();
+    if (c->events_ok)
+        for (int i = 0; i < kEventSets; i++)
+            for (int j = 0; j <= ST_COUNT; j++) (void)hipEventDestroy(c->evs[i].ev[j]);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* orbx_last_error(const orbx_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int orbx_set_stream(orbx_ctx* c, void* hip_stream)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+    return ORBX_OK;
+}
+
+int orbx_get_params(const orbx_ctx* c, int* nfeatures, float* scaleFactor, int* nlevels, int* iniThFAST, int* minThFAST)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (nfeatures) *nfeatures = c->p.nfeatures;
+    if (scaleFactor) *scaleFactor = (float)c->p.scaleFactor;
+    if (nlevels) *nlevels = c->p.nlevels;
+    if (iniThFAST) *iniThFAST = c->p.iniTh;
+    if (minThFAST) *minThFAST = c->p.minTh;
+    return ORBX_OK;
+}
+
+int orbx_get_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* sigma2, float* inv_sigma2,
+                    int32_t* nfeat_per_level)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    for (int i = 0; i < c->p.nlevels; i++) {
+        if (scale) scale[i] = c->p.scale[i];
+        if (inv_scale) inv_scale[i] = c->p.inv_scale[i];
+        if (sigma2) sigma2[i] = c->p.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = c->p.inv_sigma2[i];
+        if (nfeat_per_level) nfeat_per_level[i] = c->p.nfeat[i];
+    }
+    return ORBX_OK;
+}
+
+int orbx_max_keypoints(orbx_ctx* c, int w, int h, int* max_kps)
+{
+    if (!c || !max_kps) return ORBX_ERR_INVALID;
+    FrameGeom g;
+    std::vector<XTab> xt;
+    std::vector<YTab> yt;
+    const char* msg = "";
+    int rc = build_geometry(c->p, w, h, g, xt, yt, &msg);
+    if (rc != ORBX_OK) return fail(c, rc, msg);
+    *max_kps = g.kp_per_frame;
+    return ORBX_OK;
+}
+
+int orbx_level_size(const orbx_ctx* c, int w, int h, int level, int* lw, int* lh)
+{
+    if (!c || level < 0 || level >= c->p.nlevels || !lw || !lh) return ORBX_ERR_INVALID;
+    level_size(c->p, w, h, level, lw, lh);
+    return ORBX_OK;
+}
+
+int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int stride,
+                              size_t frame_stride, orbx_keypoint* d_kps, uint8_t* d_desc, int cap_per_frame,
+                              int32_t* d_n_out)
+{
+    int rc = check_frame_args(c, nframes, w, h, stride);
+    if (rc != ORBX_OK) return rc;
+    if (!d_imgs || !d_kps || !d_desc || !d_n_out || cap_per_frame < 1) return fail(c, ORBX_ERR_INVALID, "null buffer or cap < 1");
+    if (frame_stride < (size_t)stride * (size_t)h) return fail(c, ORBX_ERR_INVALID, "frame_stride smaller than one frame");
+    HIPCHECK(c, hipSetDevice(c->device));
+    return run_batch(c, d_imgs, nframes, w, h, stride, frame_stride, d_kps, d_desc, cap_per_frame, d_n_out, false);
+}
+
+int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int w, int h, int stride,
+                       orbx_keypoint* kps, uint8_t* desc, int cap_per_frame, int32_t* n_out)
+{
+    int rc = check_frame_args(c, nframes, w, h, stride);
+    if (rc != ORBX_OK) return rc;
+    if (!imgs || !kps || !desc || !n_out || cap_per_frame < 1) return fail(c, ORBX_ERR_INVALID, "null buffer or cap < 1");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t fbytes = (size_t)w * h, n = (size_t)nframes;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, c->in.ensure(n * fbytes));
+    HIPCHECK(c, c->out_kps.ensure(n * cap_per_frame * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->out_desc.ensure(n * cap_per_frame * 32));
+    HIPCHECK(c, c->out_n.ensure(n * 4));
+    for (int f = 0; f < nframes; f++) {
+        if (!imgs[f]) return fail(c, ORBX_ERR_INVALID, "null frame pointer");
+        HIPCHECK(c, hipMemcpy2DAsync(c->in.as<uint8_t>() + f * fbytes, w, imgs[f], stride, w, h, hipMemcpyHostToDevice,
+                                     c->stream));
+    }
+    rc = run_batch(c, c->in.as<uint8_t>(), nframes, w, h, w, fbytes, c->out_kps.as<orbx_keypoint>(),
+                   c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false);
+    if (rc != ORBX_OK) return rc;
+    HIPCHECK(c, hipMemcpyAsync(n_out, c->out_n.p, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(kps, c->out_kps.p, n * cap_per_frame * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(desc, c->out_desc.p, n * cap_per_frame * 32, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < nframes; f++)
+        if (n_out[f] > cap_per_frame) return fail(c, ORBX_ERR_CAPACITY, "cap_per_frame smaller than the number of keypoints");
+    return ORBX_OK;
+}
+
+int orbx_extract(orbx_ctx* c, const uint8_t* img, int w, int h, int stride, orbx_keypoint* kps, uint8_t* desc, int cap,
+                 int* n_out)
+{
+    if (!c || !n_out) return ORBX_ERR_INVALID;
+    *n_out = 0;
+    if (!img || w <= 0 || h <= 0) return ORBX_OK;   // empty image: nothing happens (src/ORBextractor.cc:1130-1131)
+    int32_t n = 0;
+    const uint8_t* imgs[1] = {img};
+    int rc = orbx_extract_batch(c, imgs, 1, w, h, stride, kps, desc, cap, &n);
+    *n_out = n;
+    return rc;
+}
+
+int orbx_compute_pyramid(orbx_ctx* c, const uint8_t* img, int w, int h, int stride)
+{
+    int rc = check_frame_args(c, 1, w, h, stride);
+    if (rc != ORBX_OK) return rc;
+    if (!img) return fail(c, ORBX_ERR_INVALID, "null image");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, c->in.ensure((size_t)w * h));
+    HIPCHECK(c, hipMemcpy2DAsync(c->in.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    rc = run_batch(c, c->in.as<uint8_t>(), 1, w, h, w, (size_t)w * h, nullptr, nullptr, 0, nullptr, true);
+    if (rc != ORBX_OK) return rc;
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+int orbx_pyramid_level(orbx_ctx* c, int frame, int level, const uint8_t** data, int* w, int* h, int* stride)
+{
+    if (!c || !data) return ORBX_ERR_INVALID;
+    if (!c->have_pyramid) return fail(c, ORBX_ERR_STATE, "no pyramid has been computed on this context");
+    if (frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->g.nlevels)
+        return fail(c, ORBX_ERR_INVALID, "frame or level out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (c->h_pyr_frame != frame) {
+        c->h_pyr.resize(c->g.pyr_frame_bytes);
+        HIPCHECK(c, hipMemcpyAsync(c->h_pyr.data(), c->pyr.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes,
+                                   c->g.pyr_frame_bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        c->h_pyr_frame = frame;
+    }
+    const LevelGeom& L = c->g.lv[level];
+    *data = c->h_pyr.data() + L.plane_off + (size_t)kPadY * L.pitch + kPadX;
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    if (stride) *stride = L.pitch;
+    return ORBX_OK;
+}
+
+int orbx_debug_candidates(orbx_ctx* c, int frame, int level, int32_t* xyr, int cap, int* n)
+{
+    if (!c || !n) return ORBX_ERR_INVALID;
+    if (!c->have_features) return fail(c, ORBX_ERR_STATE, "no extraction has run on this context");
+    if (frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->g.nlevels)
+        return fail(c, ORBX_ERR_INVALID, "frame or level out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const FrameGeom& g = c->g;
+    const LevelGeom& L = g.lv[level];
+    int cnt = 0;
+    HIPCHECK(c, hipMemcpyAsync(&cnt, c->level_ncand.as<int>() + (size_t)frame * kMaxLevels + level, 4,
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *n = cnt;
+    if (cnt > cap) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
+    if (cnt == 0) return ORBX_OK;
+    if (!xyr) return ORBX_ERR_INVALID;
+    std::vector<uint32_t> xy(cnt);
+    std::vector<uint8_t> rs(cnt);
+    const size_t base = (size_t)frame * g.keys_per_frame + L.key_base;
+    HIPCHECK(c, hipMemcpyAsync(xy.data(), c->key_xy.as<uint32_t>() + base, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(rs.data(), c->key_resp.as<uint8_t>() + base, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < cnt; i++) {
+        xyr[3 * i] = (int32_t)(xy[i] & 0xffff);
+        xyr[3 * i + 1] = (int32_t)(xy[i] >> 16);
+        xyr[3 * i + 2] = rs[i];
+    }
+    return ORBX_OK;
+}
+
+int orbx_debug_level_counts(orbx_ctx* c, int frame, int32_t* counts)
+{
+    if (!c || !counts) return ORBX_ERR_INVALID;
+    if (!c->have_features) return fail(c, ORBX_ERR_STATE, "no extraction has run on this context");
+    if (frame < 0 || frame >= c->last_nframes) return fail(c, ORBX_ERR_INVALID, "frame out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    int32_t tmp[kMaxLevels];
+    HIPCHECK(c, hipMemcpyAsync(tmp, c->level_count.as<int>() + (size_t)frame * kMaxLevels, sizeof(tmp),
+                               hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    for (int l = 0; l < c->g.nlevels; l++) counts[l] = tmp[l];
+    return ORBX_OK;
+}
+
+int orbx_debug_blurred_level(orbx_ctx* c, int frame, int level, uint8_t* out, size_t out_size)
+{
+    if (!c || !out) return ORBX_ERR_INVALID;
+    if (!c->have_features) return fail(c, ORBX_ERR_STATE, "no extraction has run on this context");
+    if (frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->g.nlevels)
+        return fail(c, ORBX_ERR_INVALID, "frame or level out of range");
+    const LevelGeom& L = c->g.lv[level];
+    if (out_size < (size_t)L.w * L.h) return fail(c, ORBX_ERR_CAPACITY, "output buffer too small");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const uint8_t* src = c->blur.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes + L.plane_off +
+                         (size_t)kPadY * L.pitch + kPadX;
+    HIPCHECK(c, hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+int orbx_stage_times(orbx_ctx* c, const char** names, float* total_ms, int32_t* launches, int cap)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < kEventSets; i++) harvest(c, c->evs[i]);
+    int n = ST_COUNT < cap ? ST_COUNT : cap;
+    for (int s = 0; s < n; s++) {
+        if (names) names[s] = kStageNames[s];
+        if (total_ms) total_ms[s] = (float)c->stage_ms[s];
+        if (launches) launches[s] = c->stage_launches[s];
+    }
+    return n;
+}
+
+int orbx_reset_stage_times(orbx_ctx* c)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < kEventSets; i++) harvest(c, c->evs[i]);
+    for (int s = 0; s < ST_COUNT; s++) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; }
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// matching
+// ---------------------------------------------------------------------------
+int orbx_hamming(const uint32_t a[8], const uint32_t b[8])
+{
+    int d = 0;
+    for (int i = 0; i < 8; i++) d += __builtin_popcount(a[i] ^ b[i]);
+    return d;
+}
+
+int orbx_match_bruteforce_device(orbx_ctx* c, const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
+                                 const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
+                                 int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (!d_q || !d_best_idx || !d_best_dist || !d_second_dist) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (Q < 0 || T < 0 || nbatch < 1 || nbatch > 65535 || q_stride < Q || (t_stride != 0 && t_stride < T))
+        return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (T > 0 && !d_t) return fail(c, ORBX_ERR_INVALID, "null train set");
+    if (T >= (1 << 22)) return fail(c, ORBX_ERR_UNSUPPORTED, "train set of 2^22 descriptors or more");
+    if (q_stride == 0) return ORBX_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    int tsplit = match_bruteforce_tsplit(q_stride, T, nbatch);
+    if (tsplit > 1) {
+        size_t need = (size_t)nbatch * tsplit * q_stride * 8;
+        if (need > c->partial.bytes) {
+            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            HIPCHECK(c, c->partial.ensure(need));
+        }
+    }
+    launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->partial.as<uint32_t>(),
+                            d_best_idx, d_best_dist, d_second_dist, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_match_bruteforce(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, int T, int32_t* best_idx,
+                          int32_t* best_dist, int32_t* second_dist)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (Q < 0 || T < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (Q == 0) return ORBX_OK;
+    if (!q || !best_idx || !best_dist || !second_dist || (T > 0 && !t)) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, c->m0.ensure((size_t)Q * 32));
+    HIPCHECK(c, c->m1.ensure((size_t)(T > 0 ? T : 1) * 32));
+    HIPCHECK(c, c->m2.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m3.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m4.ensure((size_t)Q * 4));
+    HIPCHECK(c, hipMemcpyAsync(c->m0.p, q, (size_t)Q * 32, hipMemcpyHostToDevice, c->stream));
+    if (T > 0) HIPCHECK(c, hipMemcpyAsync(c->m1.p, t, (size_t)T * 32, hipMemcpyHostToDevice, c->stream));
+    int rc = orbx_match_bruteforce_device(c, c->m0.as<uint32_t>(), Q, Q, nullptr, c->m1.as<uint32_t>(), T, T, nullptr, 1,
+                                          c->m2.as<int32_t>(), c->m3.as<int32_t>(), c->m4.as<int32_t>());
+    if (rc != ORBX_OK) return rc;
+    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m2.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m3.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(second_dist, c->m4.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+static int upload_csr(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, int T, const int32_t* cand_off,
+                      const int32_t* cand_idx, const int32_t* t_octave, int* ncand_out)
+{
+    if (!q || !cand_off || (T > 0 && !t)) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    const int ncand = cand_off[Q];
+    if (cand_off[0] != 0 || ncand < 0) return fail(c, ORBX_ERR_INVALID, "cand_off must start at 0 and be non-decreasing");
+    for (int i = 0; i < Q; i++) {
+        if (cand_off[i + 1] < cand_off[i]) return fail(c, ORBX_ERR_INVALID, "cand_off must be non-decreasing");
+        if (cand_off[i + 1] - cand_off[i] >= (1 << 22)) return fail(c, ORBX_ERR_UNSUPPORTED, "candidate list of 2^22 entries or more");
+    }
+    if (ncand > 0 && !cand_idx) return fail(c, ORBX_ERR_INVALID, "null candidate list");
+    for (int k = 0; k < ncand; k++)
+        if (cand_idx[k] < 0 || cand_idx[k] >= T) return fail(c, ORBX_ERR_INVALID, "candidate index out of range");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, c->m0.ensure((size_t)Q * 32));
+    HIPCHECK(c, c->m1.ensure((size_t)(T > 0 ? T : 1) * 32));
+    HIPCHECK(c, c->m5.ensure((size_t)(Q + 1) * 4));
+    HIPCHECK(c, c->m6.ensure((size_t)(ncand > 0 ? ncand : 1) * 4));
+    HIPCHECK(c, c->m7.ensure((size_t)(T > 0 ? T : 1) * 4));
+    HIPCHECK(c, hipMemcpyAsync(c->m0.p, q, (size_t)Q * 32, hipMemcpyHostToDevice, c->stream));
+    if (T > 0) HIPCHECK(c, hipMemcpyAsync(c->m1.p, t, (size_t)T * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->m5.p, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    if (ncand > 0) HIPCHECK(c, hipMemcpyAsync(c->m6.p, cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice, c->stream));
+    if (t_octave && T > 0) HIPCHECK(c, hipMemcpyAsync(c->m7.p, t_octave, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
+    *ncand_out = ncand;
+    return ORBX_OK;
+}
+
+int orbx_match_windowed(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, int T, const int32_t* cand_off,
+                        const int32_t* cand_idx, const int32_t* t_octave, int32_t* best_idx, int32_t* best_dist,
+                        int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (Q < 0 || T < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (Q == 0) return ORBX_OK;
+    if (!best_idx || !best_dist || !second_dist) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    int ncand = 0;
+    int rc = upload_csr(c, q, Q, t, T, cand_off, cand_idx, t_octave, &ncand);
+    if (rc != ORBX_OK) return rc;
+    HIPCHECK(c, c->m2.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m3.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m4.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m8.ensure((size_t)Q * 4));
+    HIPCHECK(c, c->m9.ensure((size_t)Q * 4));
+    launch_match_windowed(c->m0.as<uint32_t>(), Q, c->m1.as<uint32_t>(), c->m5.as<int32_t>(), c->m6.as<int32_t>(),
+                          t_octave ? c->m7.as<int32_t>() : nullptr, c->m2.as<int32_t>(), c->m3.as<int32_t>(),
+                          c->m4.as<int32_t>(), c->m8.as<int32_t>(), c->m9.as<int32_t>(), c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m2.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m3.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(second_dist, c->m4.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    if (best_lvl) HIPCHECK(c, hipMemcpyAsync(best_lvl, c->m8.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    if (second_lvl) HIPCHECK(c, hipMemcpyAsync(second_lvl, c->m9.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+int orbx_hamming_csr(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, int T, const int32_t* cand_off,
+                     const int32_t* cand_idx, uint16_t* dist_out)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (Q < 0 || T < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (Q == 0) return ORBX_OK;
+    int ncand = 0;
+    int rc = upload_csr(c, q, Q, t, T, cand_off, cand_idx, nullptr, &ncand);
+    if (rc != ORBX_OK) return rc;
+    if (ncand == 0) return ORBX_OK;
+    if (!dist_out) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    HIPCHECK(c, c->m2.ensure((size_t)ncand * 2));
+    launch_hamming_csr(c->m0.as<uint32_t>(), Q, c->m1.as<uint32_t>(), c->m5.as<int32_t>(), c->m6.as<int32_t>(),
+                       c->m2.as<uint16_t>(), c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(dist_out, c->m2.p, (size_t)ncand * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+int orbx_stereo_match_device(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                             const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr, int nbatch, int stride,
+                             int nrows, float mbf, float mb, float min_x, int32_t* d_best_idx, int32_t* d_best_dist,
+                             float* d_u_right, float* d_depth, int32_t* d_nmatched)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist || !d_u_right || !d_depth || !d_nmatched)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (nbatch < 1 || stride < 1 || nrows < 1 || nrows > 32767) return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per image");
+    if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
+    HIPCHECK(c, hipSetDevice(c->device));
+    launch_stereo_match(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, c->p.scale, mbf, mb, min_x,
+                        d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, int nl, const orbx_keypoint* kr,
+                      const uint32_t* dr, int nr, int nrows, float mbf, float mb, float min_x, int32_t* best_idx,
+                      int32_t* best_dist, float* u_right, float* depth, int* nmatched)
+{
+    if (!c || !nmatched) return ORBX_ERR_INVALID;
+    *nmatched = 0;
+    if (nl < 0 || nr < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (nl == 0) return ORBX_OK;
+    if (!kl || !dl || !best_idx || !best_dist || !u_right || !depth || (nr > 0 && (!kr || !dr)))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < nr; i++)
+        if (kr[i].octave < 0 || kr[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "right keypoint octave out of range");
+    const int stride = nl > nr ? nl : nr;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const size_t S = (size_t)stride;
+    HIPCHECK(c, c->m0.ensure(S * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->m1.ensure(S * 32));
+    HIPCHECK(c, c->m2.ensure(S * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->m3.ensure(S * 32));
+    HIPCHECK(c, c->m4.ensure(16));
+    HIPCHECK(c, c->m5.ensure(S * 4));
+    HIPCHECK(c, c->m6.ensure(S * 4));
+    HIPCHECK(c, c->m7.ensure(S * 4));
+    HIPCHECK(c, c->m8.ensure(S * 4));
+    int32_t counts[3] = {nl, nr, 0};
+    HIPCHECK(c, hipMemcpyAsync(c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->m1.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, c->stream));
+    if (nr > 0) {
+        HIPCHECK(c, hipMemcpyAsync(c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(c->m3.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHECK(c, hipMemcpyAsync(c->m4.p, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+    int rc = orbx_stereo_match_device(c, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
+                                      c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1, stride,
+                                      nrows, mbf, mb, min_x, c->m5.as<int32_t>(), c->m6.as<int32_t>(), c->m7.as<float>(),
+                                      c->m8.as<float>(), c->m4.as<int32_t>() + 2);
+    if (rc != ORBX_OK) return rc;
+    int32_t nm = 0;
+    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m5.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m6.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(u_right, c->m7.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(depth, c->m8.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(&nm, c->m4.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *nmatched = nm;
+    return ORBX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,60 @@
+// orbx_common.hpp -- geometry and parameter tables shared by host code and kernels.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+namespace orbx {
+
+constexpr int kMaxLevels = 8;          // pyramid levels supported by one launch descriptor
+constexpr int kEdge = 19;              // EDGE_THRESHOLD, src/ORBextractor.cc:72
+constexpr int kHalfPatch = 15;         // HALF_PATCH_SIZE, src/ORBextractor.cc:71
+constexpr int kPatch = 31;             // PATCH_SIZE, src/ORBextractor.cc:70
+constexpr int kDetBorder = 16;         // minBorderX/Y = EDGE_THRESHOLD-3, src/ORBextractor.cc:1036
+constexpr int kPadX = 32;              // left/right padding of a pyramid plane row (>= kEdge, keeps rows dword-friendly)
+constexpr int kPadY = kEdge;           // top/bottom padding of a pyramid plane
+constexpr int kMaxNodes = 2048;        // quadtree nodes one workgroup can hold in LDS
+constexpr int kPatchPixels = 749;      // pixels of the circular orientation patch
+
+// One pyramid level of one frame geometry (identical for every frame of a batch).
+struct LevelGeom {
+    int w, h;              // level image size
+    int pitch;             // bytes per plane row (w + 2*kPadX rounded up to 64)
+    int rows;              // plane rows (h + 2*kPadY)
+    uint32_t plane_off;    // byte offset of the plane inside one frame's pyramid block
+    // detection region [16, w-16) x [16, h-16) and its cell grid (src/ORBextractor.cc:1036-1050)
+    int width, height;     // region size; 0 if the level is too small to be searched
+    int nCols, nRows, wCell, hCell;
+    int cell_base;         // index of this level's first cell in the per-frame cell array
+    int cell_cap;          // candidate slots per cell
+    uint32_t cand_base;    // first candidate slot of this level inside one frame (cells * cell_cap)
+    uint32_t key_base;     // first compacted key of this level inside one frame
+    uint32_t key_cap;      // keys this level can hold (= ncells * cell_cap)
+    // quadtree (src/ORBextractor.cc:488-512)
+    int nfeat;             // N = mnFeaturesPerLevel[level]
+    int nIni;
+    float hX;
+    int kp_base;           // first retained-keypoint slot of this level inside one frame
+    int kp_cap;            // retained-keypoint slots: max(N+3, 4*nIni)
+    // resize tables of this level (index into the table buffers), level > 0 only
+    uint32_t xtab_off;     // per destination column: xofs (u16) | pad, alpha0 (i16), alpha1 (i16)
+    uint32_t ytab_off;     // per destination row: y0 (u16), y1 (u16), beta0 (i16), beta1 (i16)
+    float scale;           // mvScaleFactor[level]
+    float patch_size;      // (int)(31 * scale) as float
+};
+
+struct FrameGeom {
+    int nlevels;
+    int iniTh, minTh;
+    int ncells;                 // cells per frame, all levels
+    uint32_t pyr_frame_bytes;   // bytes of one frame's pyramid block
+    uint32_t cand_per_frame;    // candidate slots per frame
+    uint32_t keys_per_frame;    // compacted key slots per frame
+    int kp_per_frame;           // retained-keypoint slots per frame
+    int max_nodes;              // largest kp_cap+4 over levels (quadtree LDS sizing)
+    LevelGeom lv[kMaxLevels];
+};
+
+struct XTab { uint16_t xofs; uint16_t pad; int16_t a0, a1; };   // 8 bytes
+struct YTab { uint16_t y0, y1; int16_t b0, b1; };                // 8 bytes
+
+} // namespace orbx

@@ -1,0 +1,845 @@
+// orbx_kernels.hip -- gfx950 kernels of the ORB extraction path.
+//
+// Stage order of one batch (every kernel covers all frames of the batch):
+//   k_pyr_level0   copyMakeBorder of the input into level 0        (src/ORBextractor.cc:1212-1213)
+//   k_pyr_resize   level l from level l-1 + REFLECT_101 border     (:1205-1208)
+//   k_blur         7x7 Gaussian of every level                     (:1169-1170)
+//   k_fast_cells   per-cell FAST-9/16 + NMS + threshold fallback   (:1052-1101)
+//   k_quadtree     DistributeOctTree                               (:488-711)
+//   k_orient_desc  IC_Angle + rBRIEF + output assembly             (:74-150, :1109-1124, :1173-1188)
+//
+// All arithmetic that decides a result is integer, or float written with
+// explicit round-to-nearest intrinsics (no contraction), so that results are
+// bit-identical to a scalar evaluation of the same expressions.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+#include "orbx_common.hpp"
+#include "orbx_kernels.hpp"
+
+namespace orbx {
+
+// ---------------------------------------------------------------------------
+// constant tables
+// ---------------------------------------------------------------------------
+__constant__ int8_t c_pattern[256 * 4] = {
+#include "orb_pattern.inc"
+};
+__constant__ int8_t c_patch_du[kPatchPixels + 3];
+__constant__ int8_t c_patch_dv[kPatchPixels + 3];
+__constant__ int c_gauss[8];
+
+int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, hipStream_t s)
+{
+    hipError_t e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_du), du, kPatchPixels, 0, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_dv), dv, kPatchPixels, 0, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_gauss), gauss7, 7 * sizeof(int), 0, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipStreamSynchronize(s);
+}
+
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101)
+__device__ __forceinline__ int reflect101(int p, int len)
+{
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// pyramid
+// ---------------------------------------------------------------------------
+// grid (ceil(pitch/4/256), plane rows, frames); one thread = 4 plane bytes
+__global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ in, int stride, size_t frame_stride,
+                                                    uint8_t* __restrict__ pyr, FrameGeom g)
+{
+    const LevelGeom& L = g.lv[0];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int row = blockIdx.y;
+    if (x4 >= L.pitch) return;
+    const int sy = reflect101(row - kPadY, L.h);
+    const uint8_t* src = in + (size_t)blockIdx.z * frame_stride + (size_t)sy * stride;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int sx = reflect101(x4 + k - kPadX, L.w);
+        v |= (uint32_t)src[sx] << (8 * k);
+    }
+    uint8_t* dst = pyr + (size_t)blockIdx.z * g.pyr_frame_bytes + L.plane_off + (size_t)row * L.pitch + x4;
+    *reinterpret_cast<uint32_t*>(dst) = v;
+}
+
+// OpenCV 8-bit bilinear: horizontal pass in 1/2048 units without rounding,
+// vertical pass ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.
+__global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, FrameGeom g, int level,
+                                                    const XTab* __restrict__ xtab, const YTab* __restrict__ ytab)
+{
+    const LevelGeom& L = g.lv[level];
+    const LevelGeom& P = g.lv[level - 1];
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int row = blockIdx.y;
+    if (x4 >= L.pitch) return;
+    uint8_t* frame = pyr + (size_t)blockIdx.z * g.pyr_frame_bytes;
+    const int dy = reflect101(row - kPadY, L.h);
+    const YTab yt = ytab[L.ytab_off + dy];
+    const uint8_t* S0 = frame + P.plane_off + (size_t)(yt.y0 + kPadY) * P.pitch + kPadX;
+    const uint8_t* S1 = frame + P.plane_off + (size_t)(yt.y1 + kPadY) * P.pitch + kPadX;
+    const int b0 = yt.b0, b1 = yt.b1;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int dx = reflect101(x4 + k - kPadX, L.w);
+        const XTab xt = xtab[L.xtab_off + dx];
+        int h0 = S0[xt.xofs] * xt.a0 + S0[xt.xofs + 1] * xt.a1;   // a1 == 0 where xofs+1 leaves the image
+        int h1 = S1[xt.xofs] * xt.a0 + S1[xt.xofs + 1] * xt.a1;
+        int o = (((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2;
+        v |= (uint32_t)(o & 0xff) << (8 * k);
+    }
+    uint8_t* dst = frame + L.plane_off + (size_t)row * L.pitch + x4;
+    *reinterpret_cast<uint32_t*>(dst) = v;
+}
+
+// ---------------------------------------------------------------------------
+// 7x7 Gaussian blur, sigma 2, 8.8 fixed-point taps, exact integer sums,
+// dst = min(255, (acc + 32768) >> 16).  Reads the REFLECT_101 border that is
+// stored in the plane.  One workgroup = one 64 x 32 output tile.
+// ---------------------------------------------------------------------------
+constexpr int kBlurTW = 64, kBlurTH = 32;
+
+__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                              FrameGeom g, TileMap tm)
+{
+    __shared__ uint32_t s_in[(kBlurTH + 6) * 18];            // 38 rows x 72 bytes
+    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];        // horizontal sums
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+        if (l < g.nlevels && (int)blockIdx.x >= tm.base[l]) level = l;
+    const LevelGeom& L = g.lv[level];
+    const int t = blockIdx.x - tm.base[level];
+    const int tx = t % tm.tiles_x[level], ty = t / tm.tiles_x[level];
+    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+    const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
+    const uint8_t* plane = pyr + fbase;
+    const int tid = threadIdx.x;
+
+    // input tile: plane rows kPadY+y0-3 .. +38, plane cols kPadX+x0-4 .. +72 (dword aligned)
+    for (int i = tid; i < (kBlurTH + 6) * 18; i += 256) {
+        int r = i / 18, c = i - r * 18;
+        int prow = kPadY + y0 - 3 + r;
+        int pcol = kPadX + x0 - 4 + 4 * c;
+        uint32_t v = 0;
+        if (prow < L.rows && pcol + 4 <= L.pitch)
+            v = *reinterpret_cast<const uint32_t*>(plane + (size_t)prow * L.pitch + pcol);
+        s_in[i] = v;
+    }
+    __syncthreads();
+    const uint8_t* in8 = reinterpret_cast<const uint8_t*>(s_in);
+    const int k0 = c_gauss[0], k1 = c_gauss[1], k2 = c_gauss[2], k3 = c_gauss[3];
+    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
+        int r = i >> 6, c = i & 63;
+        const uint8_t* p = in8 + r * 72 + c + 1;   // pixel x0+c-3
+        int acc = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
+        s_h[i] = (uint16_t)acc;                    // <= 255*257 = 65535
+    }
+    __syncthreads();
+    const int c = tid & 63, rg = tid >> 6;          // 4 row groups of 8 rows
+    uint8_t* out = blur + fbase;
+    for (int j = 0; j < 8; j++) {
+        int r = rg * 8 + j;
+        const uint16_t* h = s_h + r * kBlurTW + c;
+        int acc = k0 * (h[0] + h[6 * kBlurTW]) + k1 * (h[kBlurTW] + h[5 * kBlurTW]) +
+                  k2 * (h[2 * kBlurTW] + h[4 * kBlurTW]) + k3 * h[3 * kBlurTW];
+        int v = (acc + 32768) >> 16;
+        v = v > 255 ? 255 : v;
+        int x = x0 + c, y = y0 + r;
+        if (x < L.w && y < L.h) out[(size_t)(kPadY + y) * L.pitch + kPadX + x] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// FAST-9/16
+// ---------------------------------------------------------------------------
+// Threshold-free corner score: S = max over the 16 arcs of 9 contiguous ring
+// pixels of max(min(v - p), min(p - v)) - 1.  "corner at threshold t" <=> S >= t,
+// and S is the score OpenCV stores for a detected corner.  With
+// maxarc(k) = max of the 9 ring pixels starting at k (and minarc likewise):
+// S = max(v - min_k maxarc(k), max_k minarc(k) - v) - 1.
+__device__ __forceinline__ int fast_score_lds(const uint8_t* c, int pitch)
+{
+    int p[16];
+    p[0] = c[3 * pitch];      p[1] = c[3 * pitch + 1];  p[2] = c[2 * pitch + 2];   p[3] = c[pitch + 3];
+    p[4] = c[3];              p[5] = c[-pitch + 3];     p[6] = c[-2 * pitch + 2];  p[7] = c[-3 * pitch + 1];
+    p[8] = c[-3 * pitch];     p[9] = c[-3 * pitch - 1]; p[10] = c[-2 * pitch - 2]; p[11] = c[-pitch - 3];
+    p[12] = c[-3];            p[13] = c[pitch - 3];     p[14] = c[2 * pitch - 2];  p[15] = c[3 * pitch - 1];
+    const int v = c[0];
+    int mx3[16], mn3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mx3[k] = max(max(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+        mn3[k] = min(min(p[k], p[(k + 1) & 15]), p[(k + 2) & 15]);
+    }
+    int mnmx = 255, mxmn = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mx9 = max(max(mx3[k], mx3[(k + 3) & 15]), mx3[(k + 6) & 15]);
+        int mn9 = min(min(mn3[k], mn3[(k + 3) & 15]), mn3[(k + 6) & 15]);
+        mnmx = min(mnmx, mx9);
+        mxmn = max(mxmn, mn9);
+    }
+    return max(v - mnmx, mxmn - v) - 1;
+}
+
+constexpr int kCellMax = 64;                       // largest cell side supported
+constexpr int kTilePitch = kCellMax + 6 + 6;       // LDS row pitch of the pixel tile (bytes, multiple of 4)
+constexpr int kScorePitch = kCellMax + 4;          // LDS row pitch of the score tile
+
+// One workgroup per (cell, frame).  The cells' tested areas tile
+// [3,width-3) x [3,height-3) of the detection region; a non-maximum test sees
+// score 0 outside its own cell's area (each cell is a separate cv::FAST call in
+// the reference).  Output: the cell's keypoints in row-major order, packed
+// (y_local << 16 | x_local << 8 | score), and their count.
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, FrameGeom g,
+                                                    uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
+{
+    __shared__ uint32_t s_tile[(kCellMax + 6) * (kTilePitch / 4)];
+    __shared__ uint8_t s_score[(kCellMax + 2) * kScorePitch];
+    __shared__ int s_wcount[4];
+    __shared__ int s_any_ini;
+
+    const int tid = threadIdx.x;
+    const int cell = blockIdx.x, f = blockIdx.y;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+        if (l < g.nlevels && g.lv[l].width > 0 && cell >= g.lv[l].cell_base) level = l;
+    const LevelGeom& L = g.lv[level];
+    const int cl = cell - L.cell_base;
+    const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
+    // tested area of this cell, relative to the detection origin (16,16)
+    const int tx0 = cj * L.wCell + 3, tx1 = min((cj + 1) * L.wCell + 3, L.width - 3);
+    const int ty0 = ci * L.hCell + 3, ty1 = min((ci + 1) * L.hCell + 3, L.height - 3);
+    const int cw = tx1 - tx0, ch = ty1 - ty0;
+    int* count_out = cell_count + (size_t)f * g.ncells + cell;
+    if (cw <= 0 || ch <= 0) {
+        if (tid == 0) *count_out = 0;
+        return;
+    }
+    // pixel tile with the 3-pixel ring margin, fetched as aligned dwords
+    const uint8_t* plane = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off;
+    const int pcol0 = kPadX + kDetBorder + tx0 - 3;       // plane column of tile column 0
+    const int prow0 = kPadY + kDetBorder + ty0 - 3;
+    const int acol0 = pcol0 & ~3, ox = pcol0 - acol0;
+    const int ndw = (ox + cw + 6 + 3) >> 2;
+    const int th = ch + 6;
+    for (int i = tid; i < th * ndw; i += 256) {
+        int r = i / ndw, c = i - r * ndw;
+        s_tile[r * (kTilePitch / 4) + c] =
+            *reinterpret_cast<const uint32_t*>(plane + (size_t)(prow0 + r) * L.pitch + acol0 + 4 * c);
+    }
+    // score tile with a zero ring
+    for (int i = tid; i < (ch + 2) * kScorePitch; i += 256) s_score[i] = 0;
+    if (tid == 0) s_any_ini = 0;
+    __syncthreads();
+
+    const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
+    const int npix = cw * ch;
+    for (int i = tid; i < npix; i += 256) {
+        int py = i / cw, px = i - py * cw;
+        int s = fast_score_lds(tile8 + (py + 3) * kTilePitch + px + 3 + ox, kTilePitch);
+        s_score[(py + 1) * kScorePitch + px + 1] = (uint8_t)((s >= g.minTh && s > 0) ? s : 0);
+    }
+    __syncthreads();
+
+    // strict 8-neighbour maxima; does the cell own one with score >= iniTh ?
+    uint32_t is_max = 0;   // bit k: pixel tid + 256*k
+    int any_ini = 0;
+    for (int i = tid, k = 0; i < npix; i += 256, k++) {
+        int py = i / cw, px = i - py * cw;
+        const uint8_t* sc = s_score + (py + 1) * kScorePitch + px + 1;
+        int s = sc[0];
+        if (s > 0 && s > sc[-1] && s > sc[1] &&
+            s > sc[-kScorePitch - 1] && s > sc[-kScorePitch] && s > sc[-kScorePitch + 1] &&
+            s > sc[kScorePitch - 1] && s > sc[kScorePitch] && s > sc[kScorePitch + 1]) {
+            is_max |= 1u << k;
+            any_ini |= (s >= g.iniTh);
+        }
+    }
+    if (any_ini) s_any_ini = 1;
+    __syncthreads();
+    const int use_ini = s_any_ini;
+
+    // ordered compaction (row-major inside the cell)
+    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
+    const int lane = tid & 63, wave = tid >> 6;
+    int base = 0;
+    for (int i0 = 0, k = 0; i0 < npix; i0 += 256, k++) {
+        int i = i0 + tid;
+        int py = 0, px = 0, s = 0, keep = 0;
+        if (i < npix && ((is_max >> k) & 1)) {
+            py = i / cw;
+            px = i - py * cw;
+            s = s_score[(py + 1) * kScorePitch + px + 1];
+            keep = !use_ini || s >= g.iniTh;
+        }
+        unsigned long long bal = __ballot(keep);
+        __syncthreads();
+        if (lane == 0) s_wcount[wave] = __popcll(bal);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            int c = s_wcount[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if (keep) {
+            int pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+        }
+        base += total;
+    }
+    if (tid == 0) *count_out = min(base, L.cell_cap);
+}
+
+// ---------------------------------------------------------------------------
+// block-wide scans (blockDim.x == 256)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread; tmp = 4 ints of LDS
+__device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
+{
+    const int incl = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int t = tmp[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+
+// in-place exclusive scan of an LDS array; returns the total to every thread
+__device__ __forceinline__ int lds_excl_scan(int* a, int n, int* tmp)
+{
+    const int chunk = (n + 255) >> 8;
+    const int b = min((int)threadIdx.x * chunk, n), e = min(b + chunk, n);
+    int s = 0;
+    for (int i = b; i < e; i++) s += a[i];
+    int tot;
+    int base = block_excl_scan(s, tmp, &tot);
+    for (int i = b; i < e; i++) {
+        int t = a[i];
+        a[i] = base;
+        base += t;
+    }
+    __syncthreads();
+    return tot;
+}
+
+// ---------------------------------------------------------------------------
+// DistributeOctTree (src/ORBextractor.cc:488-711) as array passes.
+//
+// The std::list of the reference is an array in list order.  One step splits a
+// set of nodes; the new list is "children of the node processed last first,
+// each as n4,n3,n2,n1, then the untouched nodes in their old order".  While
+// |L| + 3*(expandable nodes) <= N every multi-key node is split (processing
+// order = list order); afterwards the expandable nodes created by the previous
+// step are split in (size, creation) descending order up to and including the
+// first one that brings |L| to N -- found with a scan, because a split grows
+// |L| by (non-empty children - 1) independently of the other splits.  Among
+// nodes of equal size the one created later goes first (the reference orders
+// equal sizes by heap address, :633).
+// One workgroup per (level, frame).
+// ---------------------------------------------------------------------------
+struct QNode { short x0, x1, y0, y1; };
+
+__device__ __forceinline__ int ceil_half(int d)
+{
+    // ceil(static_cast<float>(d) / 2) for integer d (src/ORBextractor.cc:433-434)
+    return (int)ceilf(__fdiv_rn((float)d, 2.0f));
+}
+
+__global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
+                                                  const int* __restrict__ cell_count, int* __restrict__ cell_off,
+                                                  uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
+                                                  uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
+                                                  int* __restrict__ level_count, int* __restrict__ level_ncand)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int level = blockIdx.x, f = blockIdx.y;
+    const LevelGeom& L = g.lv[level];
+    const int tid = threadIdx.x;
+    if (level >= g.nlevels || L.width == 0) {
+        if (tid == 0) { level_count[f * kMaxLevels + level] = 0; level_ncand[f * kMaxLevels + level] = 0; }
+        return;
+    }
+    const int M = g.max_nodes;
+    // LDS carve-up (8-byte items first; s_best shares s_cc, s_key shares s_C)
+    QNode* s_rect = reinterpret_cast<QNode*>(smem);                                     // 2*M
+    int* s_cc = reinterpret_cast<int*>(s_rect + 2 * M);                                 // 4*M
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(s_cc);           // M (after the last step)
+    int* s_cnt = s_cc + 4 * M;                                                          // 2*M
+    int* s_A = s_cnt + 2 * M;                                                           // M
+    int* s_B = s_A + M;                                                                 // M
+    int* s_C = s_B + M;                                                                 // M
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                                 // M (only while ranking)
+    int* s_var = s_C + M;                                                               // 16
+    short* s_cidx = reinterpret_cast<short*>(s_var + 16);                               // 2*M
+    unsigned short* s_childpos = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);     // 4*M
+    unsigned short* s_newpos = s_childpos + 4 * M;                                      // M
+    unsigned short* s_order = s_newpos + M;                                             // M
+    unsigned short* s_cand = s_order + M;                                               // M
+    unsigned char* s_fl = reinterpret_cast<unsigned char*>(s_cand + M);                 // M
+    int* s_tmp = s_var;          // [0..3] scan scratch
+    // s_var[4]=size [5]=phase2 [6]=finish [7]=cntlt
+
+    const int N = L.nfeat;
+    const int ncell = L.nCols * L.nRows;
+    const int* ccount = cell_count + (size_t)f * g.ncells + L.cell_base;
+    int* coff = cell_off + (size_t)f * g.ncells + L.cell_base;
+    const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
+    uint32_t* kxy = key_xy + (size_t)f * g.keys_per_frame + L.key_base;
+    uint8_t* kresp = key_resp + (size_t)f * g.keys_per_frame + L.key_base;
+    uint16_t* knode = key_node + (size_t)f * g.keys_per_frame + L.key_base;
+
+    // ---- gather the cells' lists into one list in the reference's append order
+    int n;
+    {
+        const int chunk = (ncell + 255) >> 8;
+        const int b = min(tid * chunk, ncell), e = min(b + chunk, ncell);
+        int s = 0;
+        for (int c = b; c < e; c++) s += ccount[c];
+        int base = block_excl_scan(s, s_tmp, &n);
+        for (int c = b; c < e; c++) {
+            coff[c] = base;
+            base += ccount[c];
+        }
+        __syncthreads();
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int c = wave; c < ncell; c += 4) {
+            const int cnt = ccount[c], o = coff[c];
+            const int ci = c / L.nCols, cj = c - ci * L.nCols;
+            for (int k = lane; k < cnt; k += 64) {
+                uint32_t u = cands[(size_t)c * L.cell_cap + k];
+                int x = cj * L.wCell + 3 + (int)((u >> 8) & 0xff);
+                int y = ci * L.hCell + 3 + (int)(u >> 16);
+                kxy[o + k] = (uint32_t)x | ((uint32_t)y << 16);
+                kresp[o + k] = (uint8_t)(u & 0xff);
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) level_ncand[f * kMaxLevels + level] = n;
+
+    // ---- root nodes (:492-534)
+    const int nIni = L.nIni;
+    const float hX = L.hX;
+    for (int r = tid; r < nIni; r += 256) s_A[r] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        int x = (int)(kxy[i] & 0xffff);
+        int r = (int)__fdiv_rn((float)x, hX);
+        r = min(max(r, 0), nIni - 1);
+        atomicAdd(&s_A[r], 1);
+        knode[i] = (uint16_t)r;
+    }
+    __syncthreads();
+    for (int r = tid; r < nIni; r += 256) s_B[r] = s_A[r] > 0;
+    __syncthreads();
+    int size = lds_excl_scan(s_B, nIni, s_tmp);
+    int cur = 0;
+    for (int r = tid; r < nIni; r += 256)
+        if (s_A[r] > 0) {
+            int pos = s_B[r];
+            QNode q;
+            q.x0 = (short)(int)__fmul_rn(hX, (float)r);
+            q.x1 = (short)(int)__fmul_rn(hX, (float)(r + 1));
+            q.y0 = 0;
+            q.y1 = (short)L.height;
+            s_rect[pos] = q;
+            s_cnt[pos] = s_A[r];
+            s_cidx[pos] = -1;
+        }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) knode[i] = (uint16_t)s_B[knode[i]];
+    if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
+    __syncthreads();
+
+    // ---- splitting steps
+    while (true) {
+        size = s_var[4];
+        const int phase2 = s_var[5];
+        QNode* rc = s_rect + cur * M;
+        QNode* rn = s_rect + (cur ^ 1) * M;
+        int* cc_cur = s_cnt + cur * M;
+        int* cn_nxt = s_cnt + (cur ^ 1) * M;
+        short* ci_cur = s_cidx + cur * M;
+        short* ci_nxt = s_cidx + (cur ^ 1) * M;
+
+        // a. nodes that may be split in this step; clear child counts
+        for (int p = tid; p < size; p += 256) {
+            int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
+            s_fl[p] = (unsigned char)e;
+            s_A[p] = e;
+            s_cc[4 * p] = 0; s_cc[4 * p + 1] = 0; s_cc[4 * p + 2] = 0; s_cc[4 * p + 3] = 0;
+        }
+        if (tid == 0) s_var[7] = 0;
+        __syncthreads();
+        // b. child occupancy (DivideNode :431-476)
+        for (int i = tid; i < n; i += 256) {
+            int p = knode[i] & 0x7ff;
+            if (s_fl[p]) {
+                QNode q = rc[p];
+                uint32_t xy = kxy[i];
+                int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
+                int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
+                int qd = (x < q.x0 + hx ? 0 : 1) + (y < q.y0 + hy ? 0 : 2);
+                atomicAdd(&s_cc[4 * p + qd], 1);
+                knode[i] = (uint16_t)(p | (qd << 11));
+            }
+        }
+        __syncthreads();
+        // c. processing order of the parents
+        int norder = lds_excl_scan(s_A, size, s_tmp);   // s_A[p] = index among flagged nodes, list order
+        if (!phase2) {
+            for (int p = tid; p < size; p += 256)
+                if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
+            __syncthreads();
+        } else {
+            const int m = norder;
+            for (int p = tid; p < size; p += 256)
+                if (s_fl[p]) {
+                    s_cand[s_A[p]] = (unsigned short)p;
+                    s_key[s_A[p]] = ((uint32_t)cc_cur[p] << 11) | (uint32_t)ci_cur[p];
+                }
+            __syncthreads();
+            // rank in (size, creation) descending order; keys are distinct
+            for (int i = tid; i < m; i += 256) {
+                uint32_t ki = s_key[i];
+                int r = 0;
+                for (int j = 0; j < m; j++) r += s_key[j] > ki;
+                s_order[r] = s_cand[i];
+            }
+            __syncthreads();
+            // growth of |L| per split, in processing order; first index reaching N
+            for (int s = tid; s < m; s += 256) {
+                int p = s_order[s];
+                s_B[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0) - 1;
+                s_C[s] = s_B[s];
+            }
+            __syncthreads();
+            lds_excl_scan(s_C, m, s_tmp);
+            int below = 0;
+            for (int s = tid; s < m; s += 256) below += (size + s_C[s] + s_B[s] < N);
+            if (below) atomicAdd(&s_var[7], below);
+            __syncthreads();
+            norder = min(s_var[7] + 1, m);
+            for (int p = tid; p < size; p += 256) s_fl[p] = 0;
+            __syncthreads();
+            for (int s = tid; s < norder; s += 256) s_fl[s_order[s]] = 1;
+            __syncthreads();
+        }
+        // d. positions: children per parent (s_A), expandable children per parent (s_B), untouched nodes (s_C)
+        for (int s = tid; s < norder; s += 256) {
+            int p = s_order[s];
+            s_A[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
+            s_B[s] = (s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1);
+        }
+        for (int p = tid; p < size; p += 256) s_C[p] = !s_fl[p];
+        __syncthreads();
+        const int totalch = lds_excl_scan(s_A, norder, s_tmp);
+        const int ncreated = lds_excl_scan(s_B, norder, s_tmp);
+        const int nold = lds_excl_scan(s_C, size, s_tmp);
+        const int newsize = totalch + nold;
+        // e. build the next list
+        for (int s = tid; s < norder; s += 256) {
+            int p = s_order[s];
+            QNode q = rc[p];
+            int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
+            int nch = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
+            int pos = totalch - (s_A[s] + nch);   // children of later parents come first
+#pragma unroll
+            for (int qd = 3; qd >= 0; qd--)
+                if (s_cc[4 * p + qd] > 0) {
+                    QNode c;
+                    c.x0 = (qd & 1) ? (short)(q.x0 + hx) : q.x0;
+                    c.x1 = (qd & 1) ? q.x1 : (short)(q.x0 + hx);
+                    c.y0 = (qd & 2) ? (short)(q.y0 + hy) : q.y0;
+                    c.y1 = (qd & 2) ? q.y1 : (short)(q.y0 + hy);
+                    rn[pos] = c;
+                    cn_nxt[pos] = s_cc[4 * p + qd];
+                    ci_nxt[pos] = -1;
+                    s_childpos[4 * p + qd] = (unsigned short)pos;
+                    pos++;
+                }
+            int cb = s_B[s];
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                if (s_cc[4 * p + qd] > 1) ci_nxt[s_childpos[4 * p + qd]] = (short)(cb++);
+        }
+        for (int p = tid; p < size; p += 256)
+            if (!s_fl[p]) {
+                int pos = totalch + s_C[p];
+                s_newpos[p] = (unsigned short)pos;
+                rn[pos] = rc[p];
+                cn_nxt[pos] = cc_cur[p];
+                ci_nxt[pos] = -1;
+            }
+        __syncthreads();
+        // f. move the keys
+        for (int i = tid; i < n; i += 256) {
+            int v = knode[i];
+            int p = v & 0x7ff;
+            knode[i] = s_fl[p] ? s_childpos[4 * p + (v >> 11)] : s_newpos[p];
+        }
+        // g. loop control (:618-622, :683-684)
+        if (tid == 0) {
+            s_var[4] = newsize;
+            if (newsize >= N || newsize == size) s_var[6] = 1;
+            else if (!phase2 && newsize + 3 * ncreated > N) s_var[5] = 1;
+        }
+        cur ^= 1;
+        __syncthreads();
+        if (s_var[6]) break;
+    }
+
+    // ---- best key of every node (:689-710): largest response, first key on ties
+    size = s_var[4];
+    for (int p = tid; p < size; p += 256) s_best[p] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        unsigned long long v = ((unsigned long long)kresp[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        atomicMax(&s_best[knode[i]], v);
+    }
+    __syncthreads();
+    uint2* stage = kp_stage + (size_t)f * g.kp_per_frame + L.kp_base;
+    for (int p = tid; p < size && p < L.kp_cap; p += 256) {
+        uint32_t i = 0xFFFFFFFFu - (uint32_t)(s_best[p] & 0xFFFFFFFFull);
+        stage[p] = make_uint2(kxy[i], (uint32_t)(s_best[p] >> 32));
+    }
+    if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
+}
+
+size_t quadtree_lds_bytes(int max_nodes)
+{
+    const size_t M = (size_t)max_nodes;
+    return 2 * M * sizeof(QNode) + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 +
+           2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64;
+}
+
+// ---------------------------------------------------------------------------
+// orientation + descriptor + output assembly
+// ---------------------------------------------------------------------------
+// cv::fastAtan2 (OpenCV 3.4.1 atan_f32), every operation rounded separately
+__device__ __forceinline__ float fast_atan2_deg(float y, float x)
+{
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    const float eps = (float)2.2204460492503131e-16;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = __fdiv_rn(ay, __fadd_rn(ax, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c);
+    } else {
+        c = __fdiv_rn(ax, __fadd_rn(ay, eps));
+        c2 = __fmul_rn(c, c);
+        a = __fsub_rn(90.f, __fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(__fadd_rn(__fmul_rn(p7, c2), p5), c2), p3), c2), p1), c));
+    }
+    if (x < 0) a = __fsub_rn(180.f, a);
+    if (y < 0) a = __fsub_rn(360.f, a);
+    return a;
+}
+
+// cvRound(float): round half to even
+__device__ __forceinline__ int round_rn(float v) { return __float2int_rn(v); }
+
+// 32 lanes per keypoint, 8 keypoints per workgroup.  grid (ceil(kp_per_frame/8), frames)
+__global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t* __restrict__ pyr,
+                                                     const uint8_t* __restrict__ blur,
+                                                     const uint2* __restrict__ kp_stage,
+                                                     const int* __restrict__ level_count,
+                                                     orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
+                                                     int cap, int* __restrict__ n_out)
+{
+    const int f = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 31;
+    const int slot = blockIdx.x * 8 + (tid >> 5);
+    const int* lc = level_count + f * kMaxLevels;
+    int level = -1, k = 0, prefix = 0, total = 0;
+#pragma unroll
+    for (int l = 0; l < kMaxLevels; l++) {
+        if (l < g.nlevels) {
+            const int c = lc[l];
+            if (g.lv[l].kp_cap > 0 && slot >= g.lv[l].kp_base && slot < g.lv[l].kp_base + g.lv[l].kp_cap) {
+                level = l;
+                k = slot - g.lv[l].kp_base;
+                prefix = total;
+            }
+            total += c;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) n_out[f] = total;
+    if (level < 0 || k >= lc[level]) return;
+    const int oi = prefix + k;
+    if (oi >= cap) return;
+    const LevelGeom& L = g.lv[level];
+    const uint2 st = kp_stage[(size_t)f * g.kp_per_frame + L.kp_base + k];
+    const int x = (int)(st.x & 0xffff) + kDetBorder, y = (int)(st.x >> 16) + kDetBorder;   // :1115-1116
+
+    // IC_Angle :74-101 on the un-blurred level
+    const uint8_t* img = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
+    int m10 = 0, m01 = 0;
+    for (int i = lane; i < kPatchPixels; i += 32) {
+        int du = c_patch_du[i], dv = c_patch_dv[i];
+        int val = img[dv * L.pitch + du];
+        m10 += du * val;
+        m01 += dv * val;
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {
+        m10 += __shfl_xor(m10, d, 32);
+        m01 += __shfl_xor(m01, d, 32);
+    }
+    const float angle = fast_atan2_deg((float)m01, (float)m10);
+
+    // computeOrbDescriptor :104-150 on the blurred level; lane = descriptor byte
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const float rad = __fmul_rn(angle, factorPI);
+    const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+    const uint8_t* ctr = blur + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
+    const int8_t* pat = c_pattern + lane * 32;
+    int val = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        float x0 = (float)pat[4 * j], y0 = (float)pat[4 * j + 1], x1 = (float)pat[4 * j + 2], y1 = (float)pat[4 * j + 3];
+        int r0 = round_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
+        int c0 = round_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
+        int r1 = round_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
+        int c1 = round_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
+        int t0 = ctr[r0 * L.pitch + c0];
+        int t1 = ctr[r1 * L.pitch + c1];
+        val |= (t0 < t1) << j;
+    }
+    out_desc[((size_t)f * cap + oi) * 32 + lane] = (uint8_t)val;
+    if (lane == 0) {
+        orbx_keypoint kp;
+        kp.x = (float)x;
+        kp.y = (float)y;
+        if (level != 0) {   // :1179-1186
+            kp.x = __fmul_rn(kp.x, L.scale);
+            kp.y = __fmul_rn(kp.y, L.scale);
+        }
+        kp.size = L.patch_size;
+        kp.angle = angle;
+        kp.response = (float)st.y;
+        kp.octave = level;
+        kp.class_id = -1;
+        out_kps[(size_t)f * cap + oi] = kp;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8_t* pyr, const FrameGeom& g,
+                       int nframes, hipStream_t s)
+{
+    const LevelGeom& L = g.lv[0];
+    dim3 grid((L.pitch / 4 + 255) / 256, L.rows, nframes);
+    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, in, stride, frame_stride, pyr, g);
+}
+
+void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,
+                       int nframes, hipStream_t s)
+{
+    const LevelGeom& L = g.lv[level];
+    dim3 grid((L.pitch / 4 + 255) / 256, L.rows, nframes);
+    hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab);
+}
+
+void make_blur_tilemap(const FrameGeom& g, TileMap& tm)
+{
+    int base = 0;
+    for (int l = 0; l < kMaxLevels; l++) {
+        tm.base[l] = base;
+        tm.tiles_x[l] = 1;
+        if (l < g.nlevels) {
+            tm.tiles_x[l] = (g.lv[l].w + kBlurTW - 1) / kBlurTW;
+            base += tm.tiles_x[l] * ((g.lv[l].h + kBlurTH - 1) / kBlurTH);
+        }
+    }
+    tm.base[kMaxLevels] = base;
+}
+
+void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const TileMap& tm, int nframes, hipStream_t s)
+{
+    dim3 grid(tm.base[kMaxLevels], nframes);
+    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, pyr, blur, g, tm);
+}
+
+void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
+                       int nframes, hipStream_t s)
+{
+    if (g.ncells == 0) return;
+    dim3 grid(g.ncells, nframes);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, pyr, g, cell_cand, cell_count);
+}
+
+void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
+                     uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
+                     int* level_ncand, int nframes, hipStream_t s)
+{
+    dim3 grid(kMaxLevels, nframes);
+    size_t lds = quadtree_lds_bytes(g.max_nodes);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand);
+}
+
+int quadtree_prepare(int max_nodes)
+{
+    size_t lds = quadtree_lds_bytes(max_nodes);
+    if (lds > 160 * 1024) return -1;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
+void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
+                        const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
+                        int nframes, hipStream_t s)
+{
+    dim3 grid(g.kp_per_frame > 0 ? (g.kp_per_frame + 7) / 8 : 1, nframes);
+    hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, g, pyr, blur, reinterpret_cast<const uint2*>(kp_stage),
+                       level_count, out_kps, out_desc, cap, n_out);
+}
+
+} // namespace orbx

@@ -1,0 +1,52 @@
+// orbx_kernels.hpp -- host-callable launchers of the extraction kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/orbx.h"
+#include "orbx_common.hpp"
+
+namespace orbx {
+
+struct TileMap {
+    int base[kMaxLevels + 1];   // first tile of each level; [kMaxLevels] = total
+    int tiles_x[kMaxLevels];
+};
+
+struct ScaleTab { float v[kMaxLevels]; };
+
+int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, hipStream_t s);
+
+void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8_t* pyr, const FrameGeom& g,
+                       int nframes, hipStream_t s);
+void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,
+                       int nframes, hipStream_t s);
+void make_blur_tilemap(const FrameGeom& g, TileMap& tm);
+void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const TileMap& tm, int nframes, hipStream_t s);
+void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
+                       int nframes, hipStream_t s);
+size_t quadtree_lds_bytes(int max_nodes);
+int quadtree_prepare(int max_nodes);
+void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
+                     uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
+                     int* level_ncand, int nframes, hipStream_t s);
+void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
+                        const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
+                        int nframes, hipStream_t s);
+
+// matching (orbx_match.hip)
+void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
+                             const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
+                             int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
+                             int32_t* d_second_dist, hipStream_t s);
+int match_bruteforce_tsplit(int Q, int T, int nbatch);
+void launch_match_windowed(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
+                           const int32_t* d_idx, const int32_t* d_toct, int32_t* d_best_idx, int32_t* d_best_dist,
+                           int32_t* d_second_dist, int32_t* d_best_lvl, int32_t* d_second_lvl, hipStream_t s);
+void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
+                        const int32_t* d_idx, uint16_t* d_out, hipStream_t s);
+void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                         const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
+                         int nbatch, int stride, int nrows, const float* scale8, float mbf, float mb, float min_x,
+                         int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
+                         int32_t* d_nmatched, hipStream_t s);
+
+} // namespace orbx

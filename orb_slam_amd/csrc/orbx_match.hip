@@ -1,0 +1,352 @@
+// orbx_match.hip -- gfx950 kernels of the Hamming searches.
+//
+// A search result is "the first two candidates in (distance, position)
+// order", which is exactly what the reference's sequential scan
+//     if (dist < bestDist) {second = best; best = dist} else if (dist < bestDist2) second = dist
+// (src/ORBmatcher.cc:212-224) leaves behind.  Packing (distance << 22 | position)
+// into one 32-bit key turns the scan into key = min / median-of-three updates
+// that are associative, so the train set can be split over workgroups.
+// Distances are popcounts of XORed 32-bit words (v_bcnt_u32_b32 accumulates).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/orbx.h"
+#include "orbx_common.hpp"
+#include "orbx_kernels.hpp"
+
+namespace orbx {
+
+constexpr uint32_t kKeyNone = (256u << 22) | 0x3FFFFFu;   // distance 256, no index (a distance of 256 never wins: 'dist < 256')
+
+__device__ __forceinline__ int hamming256(const uint32_t q[8], const uint4 a, const uint4 b)
+{
+    return __popc(q[0] ^ a.x) + __popc(q[1] ^ a.y) + __popc(q[2] ^ a.z) + __popc(q[3] ^ a.w) +
+           __popc(q[4] ^ b.x) + __popc(q[5] ^ b.y) + __popc(q[6] ^ b.z) + __popc(q[7] ^ b.w);
+}
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
+{
+    return max(min(a, b), min(max(a, b), c));
+}
+
+// keep the two smallest keys seen so far (best <= second)
+__device__ __forceinline__ void push_key(uint32_t& best, uint32_t& second, uint32_t key)
+{
+    second = umed3(best, second, key);
+    best = min(best, key);
+}
+
+// grid (ceil(q_stride/256), tsplit, nbatch); thread = one query; the train
+// descriptor address is wave-uniform, so its loads are scalar.
+__global__ __launch_bounds__(256) void k_match_bruteforce(const uint32_t* __restrict__ q, int Q, int q_stride,
+                                                          const int32_t* __restrict__ nq,
+                                                          const uint32_t* __restrict__ t, int T, int t_stride,
+                                                          const int32_t* __restrict__ nt, int tsplit,
+                                                          uint32_t* __restrict__ partial,
+                                                          int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                          int32_t* __restrict__ second_dist)
+{
+    const int b = blockIdx.z;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int nQ = nq ? min(nq[b], q_stride) : Q;
+    const int nT = nt ? nt[b] : T;
+    const int chunk = (nT + tsplit - 1) / tsplit;
+    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
+    if (qi >= nQ) return;
+    uint32_t qd[8];
+    {
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
+        uint4 a = qp[0], c = qp[1];
+        qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
+        qd[4] = c.x; qd[5] = c.y; qd[6] = c.z; qd[7] = c.w;
+    }
+    const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)b * t_stride * 8);
+    uint32_t best = kKeyNone, second = kKeyNone;
+#pragma unroll 4
+    for (int j = j0; j < j1; j++) {
+        const uint4 a = tp[2 * j], c = tp[2 * j + 1];
+        const int d = hamming256(qd, a, c);
+        push_key(best, second, ((uint32_t)d << 22) | (uint32_t)j);
+    }
+    const size_t o = (size_t)b * q_stride + qi;
+    if (tsplit == 1) {
+        best_idx[o] = (best >> 22) >= 256u ? -1 : (int32_t)(best & 0x3FFFFFu);
+        best_dist[o] = (int32_t)(best >> 22);
+        second_dist[o] = (int32_t)(second >> 22);
+    } else {
+        uint32_t* p = partial + (((size_t)b * tsplit + blockIdx.y) * q_stride + qi) * 2;
+        p[0] = best;
+        p[1] = second;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict__ partial, int Q, int q_stride,
+                                                     const int32_t* __restrict__ nq, int tsplit,
+                                                     int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                     int32_t* __restrict__ second_dist)
+{
+    const int b = blockIdx.y;
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    const int nQ = nq ? min(nq[b], q_stride) : Q;
+    if (qi >= nQ) return;
+    uint32_t best = kKeyNone, second = kKeyNone;
+    for (int s = 0; s < tsplit; s++) {
+        const uint32_t* p = partial + (((size_t)b * tsplit + s) * q_stride + qi) * 2;
+        push_key(best, second, p[0]);
+        push_key(best, second, p[1]);
+    }
+    const size_t o = (size_t)b * q_stride + qi;
+    best_idx[o] = (best >> 22) >= 256u ? -1 : (int32_t)(best & 0x3FFFFFu);
+    best_dist[o] = (int32_t)(best >> 22);
+    second_dist[o] = (int32_t)(second >> 22);
+}
+
+int match_bruteforce_tsplit(int Q, int T, int nbatch)
+{
+    // enough workgroups to fill 256 CUs a few times over, chunks of >= 256 train descriptors
+    long qblocks = (long)((Q + 255) / 256) * nbatch;
+    long want = (2048 + qblocks - 1) / qblocks;
+    long maxsplit = T / 256;
+    if (maxsplit < 1) maxsplit = 1;
+    long s = want < maxsplit ? want : maxsplit;
+    if (s < 1) s = 1;
+    if (s > 1024) s = 1024;
+    return (int)s;
+}
+
+void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
+                             const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
+                             int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
+                             int32_t* d_second_dist, hipStream_t s)
+{
+    dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
+    hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
+                       tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+    if (tsplit > 1) {
+        dim3 g2((q_stride + 255) / 256, nbatch);
+        hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, d_partial, Q, q_stride, d_nq, tsplit, d_best_idx,
+                           d_best_dist, d_second_dist);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// windowed search over CSR candidate lists: thread = one query.  The key's
+// position field is the position in the query's list, so that the first
+// candidate in list order wins ties (src/ORBmatcher.cc:212).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_match_windowed(const uint32_t* __restrict__ q, int Q,
+                                                        const uint32_t* __restrict__ t,
+                                                        const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                        const int32_t* __restrict__ toct,
+                                                        int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                        int32_t* __restrict__ second_dist,
+                                                        int32_t* __restrict__ best_lvl, int32_t* __restrict__ second_lvl)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= Q) return;
+    uint32_t qd[8];
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+    uint4 a = qp[0], c = qp[1];
+    qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
+    qd[4] = c.x; qd[5] = c.y; qd[6] = c.z; qd[7] = c.w;
+    const int k0 = off[qi], k1 = off[qi + 1];
+    uint32_t best = kKeyNone, second = kKeyNone;
+    for (int k = k0; k < k1; k++) {
+        const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)idx[k] * 8);
+        const int d = hamming256(qd, tp[0], tp[1]);
+        push_key(best, second, ((uint32_t)d << 22) | (uint32_t)(k - k0));
+    }
+    const int bi = (best >> 22) >= 256u ? -1 : idx[k0 + (int)(best & 0x3FFFFFu)];
+    const int si = (second >> 22) >= 256u ? -1 : idx[k0 + (int)(second & 0x3FFFFFu)];
+    best_idx[qi] = bi;
+    best_dist[qi] = (int32_t)(best >> 22);
+    second_dist[qi] = (int32_t)(second >> 22);
+    if (best_lvl) best_lvl[qi] = bi < 0 ? -1 : (toct ? toct[bi] : 0);
+    if (second_lvl) second_lvl[qi] = si < 0 ? -1 : (toct ? toct[si] : 0);
+}
+
+void launch_match_windowed(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
+                           const int32_t* d_idx, const int32_t* d_toct, int32_t* d_best_idx, int32_t* d_best_dist,
+                           int32_t* d_second_dist, int32_t* d_best_lvl, int32_t* d_second_lvl, hipStream_t s)
+{
+    if (Q <= 0) return;
+    hipLaunchKernelGGL(k_match_windowed, dim3((Q + 255) / 256), dim3(256), 0, s, d_q, Q, d_t, d_off, d_idx, d_toct,
+                       d_best_idx, d_best_dist, d_second_dist, d_best_lvl, d_second_lvl);
+}
+
+__global__ __launch_bounds__(256) void k_hamming_csr(const uint32_t* __restrict__ q, int Q,
+                                                     const uint32_t* __restrict__ t,
+                                                     const int32_t* __restrict__ off, const int32_t* __restrict__ idx,
+                                                     uint16_t* __restrict__ out)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= Q) return;
+    uint32_t qd[8];
+    const uint4* qp = reinterpret_cast<const uint4*>(q + (size_t)qi * 8);
+    uint4 a = qp[0], c = qp[1];
+    qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
+    qd[4] = c.x; qd[5] = c.y; qd[6] = c.z; qd[7] = c.w;
+    for (int k = off[qi]; k < off[qi + 1]; k++) {
+        const uint4* tp = reinterpret_cast<const uint4*>(t + (size_t)idx[k] * 8);
+        out[k] = (uint16_t)hamming256(qd, tp[0], tp[1]);
+    }
+}
+
+void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
+                        const int32_t* d_idx, uint16_t* d_out, hipStream_t s)
+{
+    if (Q <= 0) return;
+    hipLaunchKernelGGL(k_hamming_csr, dim3((Q + 255) / 256), dim3(256), 0, s, d_q, Q, d_t, d_off, d_idx, d_out);
+}
+
+// ---------------------------------------------------------------------------
+// Stereo: Frame::PrepareStereoCandidates (include/Frame.h:217-251) +
+// Frame::ComputeStereoMatches_Undistorted(false) (src/Frame.cc:1262-1422)
+// without map-point priors.  One workgroup per stereo pair.  A right keypoint
+// is a candidate of left keypoint iL iff int(vL) lies in its row band
+// [max(0,floor(y-r)), min(nRows-1, ceil(y+r))], r = 2*scaleFactor[octave];
+// candidates are visited in ascending iR, as the row table lists them.
+// ---------------------------------------------------------------------------
+constexpr int kStereoMaxRight = 4096;
+
+__global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl,
+                                                      const int32_t* __restrict__ nl_arr,
+                                                      const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr,
+                                                      const int32_t* __restrict__ nr_arr, int stride, int nrows,
+                                                      ScaleTab sc, float mbf, float mb, float min_x,
+                                                      int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                      float* __restrict__ u_right, float* __restrict__ depth,
+                                                      int32_t* __restrict__ nmatched)
+{
+    __shared__ short s_minr[kStereoMaxRight], s_maxr[kStereoMaxRight];
+    __shared__ float s_ur[kStereoMaxRight];
+    __shared__ signed char s_oct[kStereoMaxRight];
+    __shared__ int s_hist[128];
+    __shared__ int s_nv, s_nmatched, s_median;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nl = min(nl_arr[b], stride), nr = min(min(nr_arr[b], stride), kStereoMaxRight);
+    kl += (size_t)b * stride; kr += (size_t)b * stride;
+    dl += (size_t)b * stride * 8; dr += (size_t)b * stride * 8;
+    best_idx += (size_t)b * stride; best_dist += (size_t)b * stride;
+    u_right += (size_t)b * stride; depth += (size_t)b * stride;
+
+    for (int i = tid; i < nr; i += 256) {
+        const orbx_keypoint k = kr[i];
+        const float r = __fmul_rn(2.0f, sc.v[min(max(k.octave, 0), kMaxLevels - 1)]);
+        const float hi = fminf((float)(nrows - 1), ceilf(__fadd_rn(k.y, r)));
+        const float lo = fmaxf(0.0f, floorf(__fsub_rn(k.y, r)));
+        s_maxr[i] = (short)(int)hi;
+        s_minr[i] = (short)(int)lo;
+        s_ur[i] = k.x;
+        s_oct[i] = (signed char)k.octave;
+    }
+    for (int i = tid; i < 128; i += 256) s_hist[i] = 0;
+    if (tid == 0) { s_nv = 0; s_nmatched = 0; }
+    __syncthreads();
+
+    const float minD = 0.0f;
+    const float maxD = __fdiv_rn(mbf, mb);
+    const int thOrbDist = (100 + 50) / 2;   // (TH_HIGH + TH_LOW) / 2
+    int my_matched = 0, my_nv = 0;
+    uint32_t accepted = 0;   // bit k: left keypoint tid + 256*k got a disparity
+    for (int iL = tid, kk = 0; iL < nl; iL += 256, kk++) {
+        const orbx_keypoint k = kl[iL];
+        int bidx = -1, bdist = 100;
+        float ur = -1.0f, dp = -1.0f;
+        const float vL = k.y, uL = k.x;
+        const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+        if (!(vL < 0 || vL > (float)(nrows - 1)) && !(maxU < min_x)) {
+            const int row = (int)vL;
+            uint32_t qd[8];
+            const uint4* qp = reinterpret_cast<const uint4*>(dl + (size_t)iL * 8);
+            uint4 a = qp[0], c = qp[1];
+            qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
+            qd[4] = c.x; qd[5] = c.y; qd[6] = c.z; qd[7] = c.w;
+            bool any = false;
+            int bestIdxR = 0;
+            for (int iR = 0; iR < nr; iR++) {
+                if (row < s_minr[iR] || row > s_maxr[iR]) continue;
+                any = true;
+                const int o = s_oct[iR];
+                if (o < k.octave - 1 || o > k.octave + 1) continue;
+                const float uR = s_ur[iR];
+                if (uR >= minU && uR <= maxU) {
+                    const uint4* tp = reinterpret_cast<const uint4*>(dr + (size_t)iR * 8);
+                    const int d = hamming256(qd, tp[0], tp[1]);
+                    if (d < bdist) { bdist = d; bestIdxR = iR; }
+                }
+            }
+            if (any) {
+                bidx = bestIdxR;
+                my_matched++;
+                if (bdist < thOrbDist) {
+                    float bestuR = s_ur[bestIdxR];
+                    float disparity = __fsub_rn(uL, bestuR);
+                    if (disparity >= minD && disparity < maxD) {
+                        if (disparity <= 0) {
+                            disparity = 0.01f;
+                            bestuR = (float)((double)uL - 0.01);
+                        }
+                        dp = __fdiv_rn(mbf, disparity);
+                        ur = bestuR;
+                        atomicAdd(&s_hist[bdist], 1);
+                        my_nv++;
+                        accepted |= 1u << kk;
+                    }
+                }
+            } else {
+                bdist = 100;
+            }
+        }
+        best_idx[iL] = bidx;
+        best_dist[iL] = bdist;
+        u_right[iL] = ur;
+        depth[iL] = dp;
+    }
+    if (my_matched) atomicAdd(&s_nmatched, my_matched);
+    if (my_nv) atomicAdd(&s_nv, my_nv);
+    __syncthreads();
+    // median of the accepted distances (element nv/2 of the sorted list), src/Frame.cc:1402-1404
+    if (tid == 0) {
+        int med = -1;
+        if (s_nv > 0) {
+            int target = s_nv / 2, cum = 0;
+            for (int d = 0; d < 128; d++) {
+                cum += s_hist[d];
+                if (cum > target) { med = d; break; }
+            }
+        }
+        s_median = med;
+    }
+    __syncthreads();
+    int removed = 0;
+    if (s_median >= 0) {
+        const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
+        for (int iL = tid, kk = 0; iL < nl; iL += 256, kk++) {
+            if ((accepted >> kk) & 1) {
+                if (!((float)best_dist[iL] < thDist)) {
+                    u_right[iL] = -1.0f;
+                    depth[iL] = -1.0f;
+                    removed++;
+                }
+            }
+        }
+    }
+    if (removed) atomicSub(&s_nmatched, removed);
+    __syncthreads();
+    if (tid == 0) nmatched[b] = s_nmatched;
+}
+
+void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                         const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
+                         int nbatch, int stride, int nrows, const float* scale8, float mbf, float mb, float min_x,
+                         int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
+                         int32_t* d_nmatched, hipStream_t s)
+{
+    ScaleTab sc;
+    for (int i = 0; i < kMaxLevels; i++) sc.v[i] = scale8[i];
+    hipLaunchKernelGGL(k_stereo_match, dim3(nbatch), dim3(256), 0, s, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, stride,
+                       nrows, sc, mbf, mb, min_x, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
+}
+
+} // namespace orbx

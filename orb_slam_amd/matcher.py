@@ -1,0 +1,95 @@
+"""Host-side mirror of the Hamming searches of ORB_SLAM2::ORBmatcher."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import KP_DTYPE, check, ptr
+
+
+def _desc(a):
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+    return a
+
+
+class ORBmatcher:
+    """DescriptorDistance and the best / second-best scans written around it
+    (src/ORBmatcher.cc).  `extractor` supplies the device context."""
+    TH_LOW = 50     # src/ORBmatcher.cc:37-39
+    TH_HIGH = 100
+    HISTO_LENGTH = 30
+
+    def __init__(self, extractor, nnratio=0.6, checkOri=True):
+        self._lib = _lib.load_library()
+        self._ex = extractor
+        self._ctx = extractor._ctx
+        self.mfNNratio = nnratio
+        self.mbCheckOrientation = checkOri
+
+    @staticmethod
+    def DescriptorDistance(a, b):
+        """ORBmatcher::DescriptorDistance (src/ORBmatcher.cc:1768-1784)"""
+        lib = _lib.load_library()
+        a = np.ascontiguousarray(a, np.uint8).reshape(32)
+        b = np.ascontiguousarray(b, np.uint8).reshape(32)
+        return lib.orbx_hamming(a.ctypes.data, b.ctypes.data)
+
+    def match_bruteforce(self, q, t):
+        q, t = _desc(q), _desc(t)
+        Q, T = len(q), len(t)
+        outs = [np.zeros(max(Q, 1), np.int32) for _ in range(3)]
+        check(self._lib, self._ctx, self._lib.orbx_match_bruteforce(
+            self._ctx, q.ctypes.data, Q, t.ctypes.data if T else None, T, *[o.ctypes.data for o in outs]))
+        return tuple(o[:Q] for o in outs)
+
+    def match_bruteforce_device(self, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, d_bi, d_bd, d_sd):
+        check(self._lib, self._ctx, self._lib.orbx_match_bruteforce_device(
+            self._ctx, ptr(d_q), Q, q_stride, ptr(d_nq), ptr(d_t), T, t_stride, ptr(d_nt), nbatch,
+            ptr(d_bi), ptr(d_bd), ptr(d_sd)))
+
+    def match_windowed(self, q, t, cand_off, cand_idx, t_octave=None):
+        q, t = _desc(q), _desc(t)
+        Q, T = len(q), len(t)
+        cand_off = np.ascontiguousarray(cand_off, np.int32)
+        cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        toct = None if t_octave is None else np.ascontiguousarray(t_octave, np.int32)
+        outs = [np.zeros(max(Q, 1), np.int32) for _ in range(5)]
+        check(self._lib, self._ctx, self._lib.orbx_match_windowed(
+            self._ctx, q.ctypes.data, Q, t.ctypes.data if T else None, T, cand_off.ctypes.data,
+            cand_idx.ctypes.data if len(cand_idx) else None, None if toct is None else toct.ctypes.data,
+            *[o.ctypes.data for o in outs]))
+        return tuple(o[:Q] for o in outs)
+
+    def hamming_csr(self, q, t, cand_off, cand_idx):
+        q, t = _desc(q), _desc(t)
+        cand_off = np.ascontiguousarray(cand_off, np.int32)
+        cand_idx = np.ascontiguousarray(cand_idx, np.int32)
+        out = np.zeros(max(len(cand_idx), 1), np.uint16)
+        check(self._lib, self._ctx, self._lib.orbx_hamming_csr(
+            self._ctx, q.ctypes.data, len(q), t.ctypes.data if len(t) else None, len(t), cand_off.ctypes.data,
+            cand_idx.ctypes.data if len(cand_idx) else None, out.ctypes.data))
+        return out[:len(cand_idx)]
+
+    def stereo_match(self, kl, dl, kr, dr, nrows, mbf, mb, min_x=0.0):
+        """PrepareStereoCandidates + ComputeStereoMatches_Undistorted(false)
+        (include/Frame.h:217-251, src/Frame.cc:1262-1422)"""
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        dl, dr = _desc(dl), _desc(dr)
+        nl, nr = len(kl), len(kr)
+        bi = np.zeros(max(nl, 1), np.int32)
+        bd = np.zeros(max(nl, 1), np.int32)
+        ur = np.zeros(max(nl, 1), np.float32)
+        dp = np.zeros(max(nl, 1), np.float32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match(
+            self._ctx, kl.ctypes.data, dl.ctypes.data, nl, kr.ctypes.data if nr else None,
+            dr.ctypes.data if nr else None, nr, nrows, mbf, mb, min_x,
+            bi.ctypes.data, bd.ctypes.data, ur.ctypes.data, dp.ctypes.data, C.byref(nm)))
+        return bi[:nl], bd[:nl], ur[:nl], dp[:nl], nm.value
+
+    def stereo_match_device(self, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, mbf, mb, min_x,
+                            d_bi, d_bd, d_ur, d_dp, d_nm):
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match_device(
+            self._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr), nbatch, stride, nrows,
+            mbf, mb, min_x, ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))

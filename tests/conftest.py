@@ -1,0 +1,31 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle_lib import Oracle
+    return Oracle(1000, 1.2, 8, 20, 7)
+
+
+@pytest.fixture(scope="session")
+def euroc_left():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "fixtures", "EuRoC_l.npy"))
+
+
+@pytest.fixture(scope="session")
+def euroc_right():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests", "fixtures", "EuRoC_r.npy"))

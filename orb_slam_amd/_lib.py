@@ -62,6 +62,25 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no
+    SONAME), distinct from the system one liborbx.so names.  Two HIP runtimes in
+    one process cannot both own the GPU, so when torch is installed its runtime
+    is put into the global symbol scope first and liborbx binds to it; without
+    torch, liborbx uses the system runtime it was linked against."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return None
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        return None
+    return None
+
+
 def load_library():
     """Load liborbx.so; raises if it has not been built (no fallback exists)."""
     global _lib
@@ -70,6 +89,7 @@ def load_library():
     path = library_path()
     if not os.path.exists(path):
         raise OrbxError(-2, "liborbx.so is not built: run `make -C orb_slam_amd/csrc` (or __graft_entry__.build())")
+    _share_torch_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the library lacks a declared symbol

@@ -1,0 +1,157 @@
+"""GPU parity tests of the Hamming searches (through the C ABI) against the CPU
+oracle: distances and (best, second-best) results are integers -> bit-exact."""
+import numpy as np
+import pytest
+
+from oracle_lib import KP_DTYPE
+from orb_slam_amd.synth import random_descriptors, map_descriptors, synthetic_stereo_pair
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ex():
+    from orb_slam_amd import ORBextractor
+    e = ORBextractor(1000, 1.2, 8, 20, 7)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def matcher(ex):
+    from orb_slam_amd import ORBmatcher
+    return ORBmatcher(ex)
+
+
+def test_descriptor_distance(matcher, oracle):
+    rng = np.random.default_rng(0)
+    from orb_slam_amd import ORBmatcher
+    z = np.zeros(32, np.uint8)
+    o = np.full(32, 255, np.uint8)
+    assert ORBmatcher.DescriptorDistance(z, z) == 0
+    assert ORBmatcher.DescriptorDistance(z, o) == 256
+    for _ in range(200):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        ref = int(np.unpackbits(a ^ b).sum())
+        assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
+
+
+@pytest.mark.parametrize("Q,T", [(1000, 1000), (1, 1), (257, 3), (64, 5000), (300, 0), (1000, 20000)])
+def test_bruteforce(matcher, oracle, Q, T):
+    q = random_descriptors(Q, 1)
+    t = map_descriptors(T, q, seed=2) if T else np.zeros((0, 32), np.uint8)
+    if T > 10:
+        t[5] = t[3]          # exact duplicates: ties must go to the lower index
+        q[0] = t[3]
+    bi, bd, sd = matcher.match_bruteforce(q, t)
+    oi, od, os_ = oracle.match_bruteforce(q, t)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_)
+
+
+def test_bruteforce_all_bits_differ(matcher, oracle):
+    q = np.zeros((3, 32), np.uint8)
+    t = np.full((4, 32), 255, np.uint8)      # distance 256 never beats the initial 256
+    bi, bd, sd = matcher.match_bruteforce(q, t)
+    oi, od, os_ = oracle.match_bruteforce(q, t)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_)
+    assert (bi == -1).all() and (bd == 256).all()
+
+
+def _random_csr(rng, Q, T, maxc):
+    counts = rng.integers(0, maxc + 1, Q)
+    counts[rng.integers(0, Q, max(1, Q // 10))] = 0        # ragged: empty lists
+    off = np.zeros(Q + 1, np.int32)
+    off[1:] = np.cumsum(counts)
+    idx = rng.integers(0, T, off[-1]).astype(np.int32)
+    return off, idx
+
+
+def test_windowed_and_csr(matcher, oracle):
+    rng = np.random.default_rng(7)
+    Q, T = 1500, 1200
+    q = random_descriptors(Q, 3)
+    t = map_descriptors(T, q, seed=4, planted=0.5)
+    t[10] = t[11] = t[12]
+    off, idx = _random_csr(rng, Q, T, 40)
+    toct = rng.integers(0, 8, T).astype(np.int32)
+    got = matcher.match_windowed(q, t, off, idx, toct)
+    ref = oracle.match_windowed(q, t, off, idx, toct)
+    for g, r, name in zip(got, ref, ["best_idx", "best_dist", "second_dist", "best_lvl", "second_lvl"]):
+        assert np.array_equal(g, r), name
+    d = matcher.hamming_csr(q, t, off, idx)
+    assert np.array_equal(d, oracle.hamming_csr(q, t, off, idx))
+    # without octaves
+    got = matcher.match_windowed(q, t, off, idx, None)
+    ref = oracle.match_windowed(q, t, off, idx, None)
+    for g, r in zip(got[:3], ref[:3]):
+        assert np.array_equal(g, r)
+
+
+def test_bruteforce_device_batched(ex, matcher, oracle):
+    torch = pytest.importorskip("torch")
+    nb, stride = 5, 700
+    rng = np.random.default_rng(11)
+    nq = rng.integers(1, stride + 1, nb).astype(np.int32)
+    nt = rng.integers(1, stride + 1, nb).astype(np.int32)
+    q = rng.integers(0, 256, (nb, stride, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nb, stride, 32), dtype=np.uint8)
+    dev = torch.device("cuda:0")
+    dq, dt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    dnq, dnt = torch.from_numpy(nq).to(dev), torch.from_numpy(nt).to(dev)
+    outs = [torch.full((nb, stride), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    matcher.match_bruteforce_device(dq, stride, stride, dnq, dt, stride, stride, dnt, nb, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    for b in range(nb):
+        oi, od, os_ = oracle.match_bruteforce(q[b, :nq[b]], t[b, :nt[b]])
+        assert np.array_equal(outs[0][b, :nq[b]].cpu().numpy(), oi)
+        assert np.array_equal(outs[1][b, :nq[b]].cpu().numpy(), od)
+        assert np.array_equal(outs[2][b, :nq[b]].cpu().numpy(), os_)
+
+
+def test_stereo_on_extracted_pair(ex, matcher, oracle):
+    left, right = synthetic_stereo_pair(752, 480, 4321)
+    kl, dl = ex(left)
+    kr, dr = ex(right)
+    assert len(kl) > 500 and len(kr) > 500
+    sf = ex.GetScaleFactors()
+    mbf, mb = 435.2 * 0.11 * 0 + 47.9, 0.11
+    maxD = np.float32(mbf) / np.float32(mb)
+    bi, bd, ur, dp, nm = matcher.stereo_match(kl, dl, kr, dr, 480, mbf, mb, 0.0)
+    oi, od = oracle.stereo_search(kl, dl, kr, dr, sf, 480, 0.0, float(maxD), 0.0)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+    on, our, odp = oracle.stereo_finish(kl, kr, oi, od, mbf, 0.0, float(maxD))
+    assert nm == on
+    assert np.array_equal(ur, our) and np.array_equal(dp, odp)
+    assert (ur >= 0).sum() > 100        # the synthetic pair really has matches
+
+
+def test_stereo_edge_cases(ex, matcher, oracle):
+    sf = ex.GetScaleFactors()
+    rng = np.random.default_rng(3)
+    n = 300
+    kl = np.zeros(n, KP_DTYPE)
+    kr = np.zeros(n, KP_DTYPE)
+    for k in (kl, kr):
+        k["x"] = rng.uniform(0, 752, n).astype(np.float32)
+        k["y"] = rng.uniform(-3, 483, n).astype(np.float32)      # some rows outside [0, nRows-1]
+        k["octave"] = rng.integers(0, 8, n)
+    dl = random_descriptors(n, 5)
+    dr = dl.copy()
+    rng.shuffle(dr)
+    kr["y"][:50] = kl["y"][:50]
+    kr["x"][:50] = kl["x"][:50] - rng.uniform(0, 30, 50).astype(np.float32)
+    kr["octave"][:50] = kl["octave"][:50]
+    dr[:50] = dl[:50]
+    mbf, mb = 40.0, 0.1
+    maxD = np.float32(mbf) / np.float32(mb)
+    bi, bd, ur, dp, nm = matcher.stereo_match(kl, dl, kr, dr, 480, mbf, mb, 100.0)
+    oi, od = oracle.stereo_search(kl, dl, kr, dr, sf, 480, 0.0, float(maxD), 100.0)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+    on, our, odp = oracle.stereo_finish(kl, kr, oi, od, mbf, 0.0, float(maxD))
+    assert nm == on and np.array_equal(ur, our) and np.array_equal(dp, odp)
+    # no right keypoints at all
+    bi, bd, ur, dp, nm = matcher.stereo_match(kl, dl, kr[:0], dr[:0], 480, mbf, mb, 0.0)
+    assert (bi == -1).all() and (ur == -1).all() and nm == 0

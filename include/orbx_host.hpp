@@ -1,0 +1,127 @@
+// orbx_host.hpp -- header-only C++ host class over the C ABI (orbx.h) with the
+// shape of ORB_SLAM2::ORBextractor (include/ORBextractor.h:71-176) but without
+// OpenCV types, so that it can be built anywhere.  include/orbx_adapter.hpp
+// layers the cv::Mat / cv::KeyPoint signatures on top of it.
+//
+// Error behaviour: the reference's operator() cannot fail short of an assert;
+// a GPU call can, so failures surface as std::runtime_error with the text of
+// orbx_last_error().
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "orbx.h"
+
+namespace orbx {
+
+struct ImageView {
+    const uint8_t* data = nullptr;
+    int cols = 0, rows = 0;
+    size_t step = 0;   // bytes per row
+    ImageView() = default;
+    ImageView(const uint8_t* d, int c, int r, size_t s) : data(d), cols(c), rows(r), step(s) {}
+    bool empty() const { return data == nullptr || cols <= 0 || rows <= 0; }
+};
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };   // include/ORBextractor.h:74-78
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+        : nlevels_(nlevels), scaleFactor_(scaleFactor), iniThFAST_(iniThFAST), minThFAST_(minThFAST)
+    {
+        int rc = orbx_create(&ctx_, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, device);
+        if (rc != ORBX_OK) throw std::runtime_error("orbx_create failed with code " + std::to_string(rc));
+        mvScaleFactor.resize(nlevels);
+        mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels);
+        mvInvLevelSigma2.resize(nlevels);
+        mnFeaturesPerLevel.resize(nlevels);
+        orbx_get_tables(ctx_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                        mvInvLevelSigma2.data(), mnFeaturesPerLevel.data());
+        mvImagePyramid.resize(nlevels);
+    }
+    ~ORBextractor() { orbx_destroy(ctx_); }
+    ORBextractor(const ORBextractor&) = delete;
+    ORBextractor& operator=(const ORBextractor&) = delete;
+
+    // operator()(image, mask, keypoints, descriptors): include/ORBextractor.h:88-90.
+    // The mask is ignored, as in the reference.  descriptors: n x 32 bytes, row i
+    // belongs to keypoints[i]; cleared when there are no keypoints.
+    void operator()(const ImageView& image, const ImageView& /*mask*/, std::vector<orbx_keypoint>& keypoints,
+                    std::vector<uint8_t>& descriptors)
+    {
+        if (image.empty()) return;   // src/ORBextractor.cc:1130-1131: outputs untouched
+        int cap = 0;
+        check(orbx_max_keypoints(ctx_, image.cols, image.rows, &cap));
+        keypoints.resize(cap);
+        descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(orbx_extract(ctx_, image.data, image.cols, image.rows, (int)image.step, keypoints.data(),
+                           descriptors.data(), cap, &n));
+        keypoints.resize(n);
+        descriptors.resize((size_t)n * 32);
+        refresh_pyramid();
+    }
+
+    // include/ORBextractor.h:143 (public: the detection-I/O path calls it on its own)
+    void ComputePyramid(const ImageView& image)
+    {
+        check(orbx_compute_pyramid(ctx_, image.data, image.cols, image.rows, (int)image.step));
+        refresh_pyramid();
+    }
+
+    int GetLevels() { return nlevels_; }
+    float GetScaleFactor() { return scaleFactor_; }
+    int GetInitThres() { return iniThFAST_; }
+    int GetMinThres() { return minThFAST_; }
+    std::vector<float> GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // mvImagePyramid (include/ORBextractor.h:138): host-readable views of the
+    // un-blurred levels of the last call, each surrounded by >= 19 REFLECT_101
+    // border pixels at the same step; valid until the next call on this object.
+    std::vector<ImageView> mvImagePyramid;
+
+    orbx_ctx* context() { return ctx_; }
+
+private:
+    void check(int rc)
+    {
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ctx_));
+    }
+    void refresh_pyramid()
+    {
+        for (int l = 0; l < nlevels_; l++) {
+            const uint8_t* d = nullptr;
+            int w = 0, h = 0, s = 0;
+            check(orbx_pyramid_level(ctx_, 0, l, &d, &w, &h, &s));
+            mvImagePyramid[l] = ImageView(d, w, h, (size_t)s);
+        }
+    }
+
+    orbx_ctx* ctx_ = nullptr;
+    int nlevels_;
+    float scaleFactor_;
+    int iniThFAST_, minThFAST_;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int32_t> mnFeaturesPerLevel;
+};
+
+// ORBmatcher::DescriptorDistance (include/ORBmatcher.h:48) on raw 32-byte rows
+inline int DescriptorDistance(const uint8_t* a, const uint8_t* b)
+{
+    uint32_t wa[8], wb[8];
+    for (int i = 0; i < 8; i++) {
+        wa[i] = (uint32_t)a[4 * i] | ((uint32_t)a[4 * i + 1] << 8) | ((uint32_t)a[4 * i + 2] << 16) | ((uint32_t)a[4 * i + 3] << 24);
+        wb[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    }
+    return orbx_hamming(wa, wb);
+}
+
+} // namespace orbx

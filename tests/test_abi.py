@@ -70,3 +70,12 @@ def test_product_does_not_reference_the_oracle():
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
     out = os.popen("ldd %s" % os.path.join(pkg, "lib", "liborbx.so")).read()
     assert "oracle" not in out
+
+
+def test_cpp_host_class_builds_against_the_abi():
+    """include/orbx_host.hpp (the C++ mirror of the reference's class) compiles
+    with plain g++ and links against liborbx.so."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", d, "host_extract"])
+    assert os.path.exists(os.path.join(d, "host_extract"))

@@ -138,3 +138,29 @@ def test_compute_pyramid_only(gpu, oracle, euroc_right):
     oracle.compute_pyramid(euroc_right)
     for l in range(8):
         assert np.array_equal(gpu.pyramid_level(l, border=19), oracle.pyramid_plane(l))
+
+
+def test_cpp_host_program(oracle, euroc_left, tmp_path):
+    """The C++ host class (include/orbx_host.hpp) gives the same result as the oracle."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "host_extract")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "host_extract"])
+    raw = tmp_path / "img.raw"
+    out = tmp_path / "out.bin"
+    euroc_left.tofile(raw)
+    subprocess.check_call([exe, str(raw), "752", "480", str(out)], timeout=100)
+    buf = out.read_bytes()
+    n, nl = np.frombuffer(buf, np.int32, 2)
+    sizes = np.frombuffer(buf, np.int32, 2 * nl, 8).reshape(nl, 2)
+    from oracle_lib import KP_DTYPE
+    kps = np.frombuffer(buf, KP_DTYPE, n, 8 + 8 * nl)
+    desc = np.frombuffer(buf, np.uint8, n * 32, 8 + 8 * nl + 28 * n).reshape(n, 32)
+    kps_o, desc_o = oracle.extract(euroc_left, literal=False)
+    assert [tuple(s) for s in sizes] == [oracle.level_size(752, 480, l) for l in range(nl)]
+    _assert_features(kps, desc, kps_o, desc_o)
+    oracle.compute_pyramid(euroc_left)
+    top = oracle.pyramid_plane(nl - 1)[19:-19, 19:-19]
+    assert buf[-1] == top[top.shape[0] // 2, top.shape[1] // 2]

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -56,7 +57,8 @@ struct orbx_ctx {
     int gw = 0, gh = 0;
     FrameGeom g;
     TileMap tm;
-    DevBuf xtab, ytab;
+    SlideMap blur_map;
+    DevBuf xtab, ytab, xtab4, ytab2;
 
     // per-batch working set
     int cap_frames = 0;
@@ -120,10 +122,11 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
 {
     if (c->gw == w && c->gh == h) return ORBX_OK;
     FrameGeom g;
-    std::vector<XTab> xt;
-    std::vector<YTab> yt;
+    ResizeTables rt;
+    std::vector<XTab>& xt = rt.xtab;
+    std::vector<YTab>& yt = rt.ytab;
     const char* msg = "";
-    int rc = build_geometry(c->p, w, h, g, xt, yt, &msg);
+    int rc = build_geometry(c->p, w, h, g, rt, &msg);
     if (rc != ORBX_OK) return fail(c, rc, msg);
     for (int l = 0; l < g.nlevels; l++)
         if (g.lv[l].key_cap >= (1u << 21)) return fail(c, ORBX_ERR_UNSUPPORTED, "a level has more than 2^21 candidate slots");
@@ -133,9 +136,14 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     HIPCHECK(c, c->ytab.ensure(yt.size() * sizeof(YTab)));
     HIPCHECK(c, hipMemcpyAsync(c->xtab.p, xt.data(), xt.size() * sizeof(XTab), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipMemcpyAsync(c->ytab.p, yt.data(), yt.size() * sizeof(YTab), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));   // xt/yt are stack-owned
+    HIPCHECK(c, c->xtab4.ensure(rt.xtab4.size() * sizeof(XTab4)));
+    HIPCHECK(c, c->ytab2.ensure(rt.ytab2.size() * sizeof(YTab2)));
+    HIPCHECK(c, hipMemcpyAsync(c->xtab4.p, rt.xtab4.data(), rt.xtab4.size() * sizeof(XTab4), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->ytab2.p, rt.ytab2.data(), rt.ytab2.size() * sizeof(YTab2), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));   // the tables are stack-owned
     c->g = g;
     make_blur_tilemap(c->g, c->tm);
+    make_slide_map(c->g, 64, c->blur_map);
     c->gw = w;
     c->gh = h;
     c->cap_frames = 0;   // per-frame sizes changed
@@ -187,8 +195,11 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     mark(ST_PYR0);
     launch_pyr_level0(d_imgs, stride, frame_stride, c->pyr.as<uint8_t>(), g, nframes, s);
     mark(ST_RESIZE);
-    for (int l = 1; l < g.nlevels; l++)
-        launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
+    const bool slide = g.resize_slide_ok && !getenv("ORBX_OLD_RESIZE");
+    for (int l = 1; l < g.nlevels; l++) {
+        if (slide) launch_resize_slide(c->pyr.as<uint8_t>(), g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
+        else launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
+    }
     c->last_nframes = nframes;
     c->have_pyramid = true;
     c->have_features = false;
@@ -198,7 +209,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         return ORBX_OK;
     }
     mark(ST_BLUR);
-    launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, s);
+    if (getenv("ORBX_OLD_BLUR")) launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, s);
+    else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, s);
     mark(ST_FAST);
     launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
     mark(ST_QUADTREE);
@@ -271,7 +283,7 @@ void orbx_destroy(orbx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
+    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9};
@@ -323,10 +335,9 @@ int orbx_max_keypoints(orbx_ctx* c, int w, int h, int* max_kps)
 {
     if (!c || !max_kps) return ORBX_ERR_INVALID;
     FrameGeom g;
-    std::vector<XTab> xt;
-    std::vector<YTab> yt;
+    ResizeTables rt;
     const char* msg = "";
-    int rc = build_geometry(c->p, w, h, g, xt, yt, &msg);
+    int rc = build_geometry(c->p, w, h, g, rt, &msg);
     if (rc != ORBX_OK) return fail(c, rc, msg);
     *max_kps = g.kp_per_frame;
     return ORBX_OK;

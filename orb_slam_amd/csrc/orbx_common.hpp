@@ -38,6 +38,8 @@ struct LevelGeom {
     // resize tables of this level (index into the table buffers), level > 0 only
     uint32_t xtab_off;     // per destination column: xofs (u16) | pad, alpha0 (i16), alpha1 (i16)
     uint32_t ytab_off;     // per destination row: y0 (u16), y1 (u16), beta0 (i16), beta1 (i16)
+    uint32_t xtab4_off;    // per destination plane dword column (XTab4), border columns included
+    uint32_t ytab2_off;    // per destination plane row (YTab2), border rows included
     float scale;           // mvScaleFactor[level]
     float patch_size;      // (int)(31 * scale) as float
 };
@@ -51,10 +53,18 @@ struct FrameGeom {
     uint32_t keys_per_frame;    // compacted key slots per frame
     int kp_per_frame;           // retained-keypoint slots per frame
     int max_nodes;              // largest kp_cap+4 over levels (quadtree LDS sizing)
+    int resize_slide_ok;        // 1 if every XTab4 window fits in 8 source bytes
     LevelGeom lv[kMaxLevels];
 };
 
 struct XTab { uint16_t xofs; uint16_t pad; int16_t a0, a1; };   // 8 bytes
 struct YTab { uint16_t y0, y1; int16_t b0, b1; };                // 8 bytes
+// Four adjacent destination columns of one plane dword: the 8 source bytes at `base` (relative to
+// source image column 0) hold every pixel they need; sel[k] is a v_perm_b32 selector that yields
+// (left pixel, right pixel) of column k as two zero-extended u16, a01[k] their weights as two u16.
+struct XTab4 { uint32_t base; uint32_t sel[4]; uint32_t a01[4]; };   // 36 bytes
+// One destination plane row: byte offsets of its two source rows inside the source plane
+// (pointing at source image column 0) and the vertical weights.
+struct YTab2 { uint32_t off0, off1; int16_t b0, b1; };               // 12 bytes
 
 } // namespace orbx

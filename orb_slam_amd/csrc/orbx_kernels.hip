@@ -103,6 +103,54 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, F
     *reinterpret_cast<uint32_t*>(dst) = v;
 }
 
+// The same resize with a lane owning 4 adjacent destination pixels (one plane
+// dword, border columns included) and walking down a band of plane rows.  Per
+// source row one unaligned 8-byte load holds every pixel the 4 columns need;
+// v_perm_b32 pulls each column's (left, right) pair out as two u16 and
+// v_dot2_u32_u16 applies the two horizontal weights.  No LDS, no barriers.
+struct __attribute__((packed)) Unaligned8 { uint32_t lo, hi; };
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint32_t a01)
+{
+    const uint32_t pq = __builtin_amdgcn_perm(s.hi, s.lo, sel);
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, pq), __builtin_bit_cast(ushort2_t, a01), 0u, false) >> 4;
+}
+
+__global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr, FrameGeom g, int level,
+                                                      const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
+                                                      int rows_per_band, int ncb)
+{
+    const LevelGeom& L = g.lv[level];
+    const LevelGeom& P = g.lv[level - 1];
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rb = item / ncb, cb = item - rb * ncb;
+    const int dwc = cb * 64 + lane;
+    const int r0 = rb * rows_per_band, r1 = min(r0 + rows_per_band, L.rows);
+    if (dwc * 4 >= L.pitch || r0 >= L.rows) return;
+    uint8_t* frame = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes;
+    const XTab4 x = xtab[L.xtab4_off + dwc];
+    const uint8_t* src = frame + P.plane_off + x.base;
+    uint8_t* dst = frame + L.plane_off + 4 * dwc;
+    const YTab2* yt = ytab + L.ytab2_off;
+    for (int r = r0; r < r1; r++) {
+        const YTab2 y = yt[r];
+        const Unaligned8 s0 = *reinterpret_cast<const Unaligned8*>(src + y.off0);
+        const Unaligned8 s1 = *reinterpret_cast<const Unaligned8*>(src + y.off1);
+        const uint32_t b0 = (uint32_t)y.b0, b1 = (uint32_t)y.b1;
+        uint32_t o = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t h0 = hpair(s0, x.sel[k], x.a01[k]);
+            const uint32_t h1 = hpair(s1, x.sel[k], x.a01[k]);
+            const uint32_t v = (((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2u) >> 2;
+            o |= (v & 0xffu) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t*>(dst + (size_t)r * L.pitch) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // 7x7 Gaussian blur, sigma 2, 8.8 fixed-point taps, exact integer sums,
 // dst = min(255, (acc + 32768) >> 16).  Reads the REFLECT_101 border that is
@@ -158,6 +206,83 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
         v = v > 255 ? 255 : v;
         int x = x0 + c, y = y0 + r;
         if (x < L.w && y < L.h) out[(size_t)(kPadY + y) * L.pitch + kPadX + x] = (uint8_t)v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Sliding-window form of the same blur: a lane owns 4 adjacent pixels (one
+// dword) of a column block and walks down a band of rows, keeping the last 7
+// horizontal sums of its pixels in registers.  No LDS, no barriers: one
+// 12-byte load, 14 byte-alignment / dot4 operations for the 4 horizontal sums,
+// 7 multiply-adds per pixel for the column, one dword store per row.
+// Work item = (level, 64-dword column block, row band); 4 items per workgroup.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void blur_hsum4(const uint8_t* p, uint32_t out[4])
+{
+    // p -> 12 bytes: pixels x-4 .. x+7 of one row
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    const uint32_t Lw = q[0], Cw = q[1], Rw = q[2];
+    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
+    const uint32_t K1 = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
+    // pixel j: window = bytes j+1 .. j+7 of (L,C,R)
+    out[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, 0u, false), false);
+    out[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, 0u, false), false);
+    out[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1,
+                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, 0u, false), false);
+    out[3] = __builtin_amdgcn_udot4(Rw, K1, __builtin_amdgcn_udot4(Cw, K0, 0u, false), false);
+}
+
+__device__ __forceinline__ uint32_t blur_vsum(uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t h4,
+                                              uint32_t h5, uint32_t h6)
+{
+    uint32_t acc = 18u * (h0 + h6) + 34u * (h1 + h5) + 49u * (h2 + h4) + 55u * h3 + 32768u;
+    acc >>= 16;
+    return acc > 255u ? 255u : acc;
+}
+
+__global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                    FrameGeom g, SlideMap sm)
+{
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= sm.base[kMaxLevels]) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+        if (l < g.nlevels && item >= sm.base[l]) level = l;
+    const LevelGeom& L = g.lv[level];
+    const int local = item - sm.base[level];
+    const int rb = local / sm.ncb[level], cb = local - rb * sm.ncb[level];
+    const int dw = cb * 64 + lane;                       // dword column inside the level image
+    if (dw * 4 >= L.w) return;
+    const int y0 = rb * sm.rows[level], y1 = min(y0 + sm.rows[level], L.h);
+    const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
+    const uint8_t* src = pyr + fbase + (size_t)(kPadY + y0 - 3) * L.pitch + kPadX + 4 * dw - 4;
+    uint8_t* dst = blur + fbase + (size_t)(kPadY + y0) * L.pitch + kPadX + 4 * dw;
+    const int pitch = L.pitch;
+    const int nsteps = (y1 - y0) + 6;
+
+    uint32_t h[7][4];
+#pragma unroll
+    for (int i = 0; i < 7; i++) { h[i][0] = h[i][1] = h[i][2] = h[i][3] = 0; }
+    for (int s0 = 0; s0 < nsteps; s0 += 7) {
+#pragma unroll
+        for (int p = 0; p < 7; p++) {
+            const int s = s0 + p;
+            if (s < nsteps) {
+                blur_hsum4(src + (size_t)s * pitch, h[p]);
+                if (s >= 6) {
+                    uint32_t o = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        o |= blur_vsum(h[(p + 1) % 7][j], h[(p + 2) % 7][j], h[(p + 3) % 7][j], h[(p + 4) % 7][j],
+                                       h[(p + 5) % 7][j], h[(p + 6) % 7][j], h[p][j]) << (8 * j);
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)(s - 6) * pitch) = o;
+                }
+            }
+        }
     }
 }
 
@@ -783,6 +908,17 @@ void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* 
     hipLaunchKernelGGL(k_pyr_resize, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab);
 }
 
+void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
+                         int nframes, hipStream_t s)
+{
+    const LevelGeom& L = g.lv[level];
+    const int rows_per_band = 16;
+    const int ncb = (L.pitch / 4 + 63) / 64;
+    const int nrb = (L.rows + rows_per_band - 1) / rows_per_band;
+    dim3 grid((ncb * nrb + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb);
+}
+
 void make_blur_tilemap(const FrameGeom& g, TileMap& tm)
 {
     int base = 0;
@@ -801,6 +937,31 @@ void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const Ti
 {
     dim3 grid(tm.base[kMaxLevels], nframes);
     hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, pyr, blur, g, tm);
+}
+
+void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
+{
+    int base = 0;
+    for (int l = 0; l < kMaxLevels; l++) {
+        sm.base[l] = base;
+        sm.ncb[l] = 1;
+        sm.rows[l] = 1;
+        if (l < g.nlevels) {
+            const int ndw = (g.lv[l].w + 3) / 4;
+            const int nrb = (g.lv[l].h + target_rows - 1) / target_rows;
+            sm.ncb[l] = (ndw + 63) / 64;
+            sm.rows[l] = (g.lv[l].h + nrb - 1) / nrb;
+            base += sm.ncb[l] * nrb;
+        }
+    }
+    sm.base[kMaxLevels] = base;
+}
+
+void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
+                       hipStream_t s)
+{
+    dim3 grid((sm.base[kMaxLevels] + 3) / 4, nframes);
+    hipLaunchKernelGGL(k_blur_slide, grid, dim3(256), 0, s, pyr, blur, g, sm);
 }
 
 void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,

@@ -11,6 +11,13 @@ struct TileMap {
     int tiles_x[kMaxLevels];
 };
 
+// work items of the sliding-window kernels: (level, 64-dword column block, row band)
+struct SlideMap {
+    int base[kMaxLevels + 1];   // first item of each level; [kMaxLevels] = total
+    int ncb[kMaxLevels];        // column blocks per level
+    int rows[kMaxLevels];       // rows per band
+};
+
 struct ScaleTab { float v[kMaxLevels]; };
 
 int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, hipStream_t s);
@@ -19,8 +26,13 @@ void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8
                        int nframes, hipStream_t s);
 void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,
                        int nframes, hipStream_t s);
+void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
+                         int nframes, hipStream_t s);
 void make_blur_tilemap(const FrameGeom& g, TileMap& tm);
 void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const TileMap& tm, int nframes, hipStream_t s);
+void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm);
+void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
+                       hipStream_t s);
 void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
                        int nframes, hipStream_t s);
 size_t quadtree_lds_bytes(int max_nodes);

@@ -102,9 +102,22 @@ static void axis_table(int src, int dst, std::vector<int>& ofs, std::vector<int1
     }
 }
 
-int build_geometry(const Params& p, int w, int h, FrameGeom& g,
-                   std::vector<XTab>& xtab, std::vector<YTab>& ytab, const char** msg)
+static int reflect101(int p, int len)
 {
+    if (len == 1) return 0;
+    while ((unsigned)p >= (unsigned)len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& tabs, const char** msg)
+{
+    std::vector<XTab>& xtab = tabs.xtab;
+    std::vector<YTab>& ytab = tabs.ytab;
+    std::vector<XTab4>& xtab4 = tabs.xtab4;
+    std::vector<YTab2>& ytab2 = tabs.ytab2;
+    xtab4.clear();
+    ytab2.clear();
+    bool slide_ok = true;
     static const char* ok = "";
     *msg = ok;
     std::memset(&g, 0, sizeof(g));
@@ -170,6 +183,25 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g,
             axis_table(P.w, L.w, ofs, c0, c1, true);
             L.xtab_off = (uint32_t)xtab.size();
             for (int d = 0; d < L.w; d++) xtab.push_back(XTab{(uint16_t)ofs[d], 0, c0[d], c1[d]});
+            // the same per plane dword column, border columns resolved through REFLECT_101
+            L.xtab4_off = (uint32_t)xtab4.size();
+            for (int dwc = 0; dwc < L.pitch / 4; dwc++) {
+                int sx[4], base = 1 << 30;
+                for (int k = 0; k < 4; k++) {
+                    sx[k] = ofs[reflect101(4 * dwc + k - kPadX, L.w)];
+                    base = std::min(base, sx[k]);
+                }
+                XTab4 e;
+                e.base = (uint32_t)base;
+                for (int k = 0; k < 4; k++) {
+                    int dx = reflect101(4 * dwc + k - kPadX, L.w);
+                    int ia = sx[k] - base, ib = ia + 1;
+                    if (ib > 7) slide_ok = false;
+                    e.sel[k] = (uint32_t)(ia & 7) | (0x0cu << 8) | ((uint32_t)(ib & 7) << 16) | (0x0cu << 24);
+                    e.a01[k] = (uint32_t)(uint16_t)c0[dx] | ((uint32_t)(uint16_t)c1[dx] << 16);
+                }
+                xtab4.push_back(e);
+            }
             axis_table(P.h, L.h, ofs, c0, c1, false);
             L.ytab_off = (uint32_t)ytab.size();
             for (int d = 0; d < L.h; d++) {
@@ -177,6 +209,15 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g,
                 int y0 = std::min(std::max(ofs[d], 0), P.h - 1);
                 int y1 = std::min(std::max(ofs[d] + 1, 0), P.h - 1);
                 ytab.push_back(YTab{(uint16_t)y0, (uint16_t)y1, c0[d], c1[d]});
+            }
+            L.ytab2_off = (uint32_t)ytab2.size();
+            for (int r = 0; r < L.rows; r++) {
+                int d = reflect101(r - kPadY, L.h);
+                int y0 = std::min(std::max(ofs[d], 0), P.h - 1);
+                int y1 = std::min(std::max(ofs[d] + 1, 0), P.h - 1);
+                if (c0[d] < 0 || c1[d] < 0) slide_ok = false;
+                ytab2.push_back(YTab2{(uint32_t)((y0 + kPadY) * P.pitch + kPadX), (uint32_t)((y1 + kPadY) * P.pitch + kPadX),
+                                      c0[d], c1[d]});
             }
         }
     }
@@ -187,6 +228,9 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g,
     g.keys_per_frame = (uint32_t)cand;
     g.kp_per_frame = kps;
     g.max_nodes = std::max(max_nodes, 64);
+    g.resize_slide_ok = slide_ok ? 1 : 0;
+    if (xtab4.empty()) xtab4.push_back(XTab4{0, {0, 0, 0, 0}, {0, 0, 0, 0}});
+    if (ytab2.empty()) ytab2.push_back(YTab2{0, 0, 0, 0});
     if (xtab.empty()) xtab.push_back(XTab{0, 0, 0, 0});
     if (ytab.empty()) ytab.push_back(YTab{0, 0, 0, 0});
     return ORBX_OK;

@@ -23,8 +23,13 @@ void level_size(const Params& p, int w, int h, int level, int* lw, int* lh);
 
 // Geometry of every level for a w x h input, and the cv::resize tables.
 // Returns 0 or a negative ORBX error code; msg explains a failure.
-int build_geometry(const Params& p, int w, int h, FrameGeom& g,
-                   std::vector<XTab>& xtab, std::vector<YTab>& ytab, const char** msg);
+struct ResizeTables {
+    std::vector<XTab> xtab;
+    std::vector<YTab> ytab;
+    std::vector<XTab4> xtab4;
+    std::vector<YTab2> ytab2;
+};
+int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& t, const char** msg);
 
 // 7-tap Gaussian (sigma 2) as 8.8 fixed point: [18,34,49,55,49,34,18]
 void gauss7_taps(int taps[7]);

@@ -58,6 +58,7 @@ struct orbx_ctx {
     FrameGeom g;
     TileMap tm;
     SlideMap blur_map;
+    FastLds fast_lds;
     DevBuf xtab, ytab, xtab4, ytab2;
 
     // per-batch working set
@@ -144,6 +145,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     c->g = g;
     make_blur_tilemap(c->g, c->tm);
     make_slide_map(c->g, 64, c->blur_map);
+    make_fast_lds(c->g, c->fast_lds);
     c->gw = w;
     c->gh = h;
     c->cap_frames = 0;   // per-frame sizes changed
@@ -212,7 +214,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     if (getenv("ORBX_OLD_BLUR")) launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, s);
     else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, s);
     mark(ST_FAST);
-    launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
     mark(ST_QUADTREE);
     launch_quadtree(g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), c->cell_off.as<int>(),
                     c->key_xy.as<uint32_t>(), c->key_resp.as<uint8_t>(), c->key_node.as<uint16_t>(), c->kp_stage.p,

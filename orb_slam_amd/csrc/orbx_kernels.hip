@@ -13,6 +13,7 @@
 // bit-identical to a scalar evaluation of the same expressions.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 #include "../../include/orbx.h"
 #include "orbx_common.hpp"
@@ -432,6 +433,135 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+// Per-cell FAST, one wavefront per cell.  Most pixels fail a 4-point necessary
+// test (an arc of 9 ring pixels always contains two adjacent compass points,
+// so a corner needs two adjacent compass pixels beyond the threshold on the
+// same side); the survivors are queued in pixel order and only they get the
+// full score.  Everything after the tile load is wave-synchronous: ballots and
+// lane prefix counts keep the queue, and therefore the output, in row-major
+// order.  Results are identical to k_fast_cells.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
+                                                        uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* s_score = smem + fl.score_off;
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(smem + fl.queue_off);
+    const int TP = fl.tile_pitch, SP = fl.score_pitch;
+
+    const int lane = threadIdx.x;
+    const int cell = blockIdx.x, f = blockIdx.y;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+        if (l < g.nlevels && g.lv[l].width > 0 && cell >= g.lv[l].cell_base) level = l;
+    const LevelGeom& L = g.lv[level];
+    const int cl = cell - L.cell_base;
+    const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
+    const int tx0 = cj * L.wCell + 3, tx1 = min((cj + 1) * L.wCell + 3, L.width - 3);
+    const int ty0 = ci * L.hCell + 3, ty1 = min((ci + 1) * L.hCell + 3, L.height - 3);
+    const int cw = tx1 - tx0, ch = ty1 - ty0;
+    int* count_out = cell_count + (size_t)f * g.ncells + cell;
+    if (cw <= 0 || ch <= 0) {
+        if (lane == 0) *count_out = 0;
+        return;
+    }
+    const uint8_t* plane = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off;
+    const int pcol0 = kPadX + kDetBorder + tx0 - 3;
+    const int prow0 = kPadY + kDetBorder + ty0 - 3;
+    const int acol0 = pcol0 & ~3, ox = pcol0 - acol0;
+    const int ndw = (ox + cw + 6 + 3) >> 2;
+    const int th = ch + 6;
+    const uint32_t rcp_ndw = (65536u + ndw - 1) / ndw;          // i / ndw for i < 2^12, ndw <= 20
+    for (int i = lane; i < th * ndw; i += 64) {
+        int r = (int)(((uint32_t)i * rcp_ndw) >> 16), c = i - r * ndw;
+        s_tile[r * (TP >> 2) + c] =
+            *reinterpret_cast<const uint32_t*>(plane + (size_t)(prow0 + r) * L.pitch + acol0 + 4 * c);
+    }
+    {
+        uint32_t* sc32 = reinterpret_cast<uint32_t*>(s_score);
+        for (int i = lane; i < ((ch + 2) * SP) >> 2; i += 64) sc32[i] = 0;
+    }
+    __syncthreads();
+
+    const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
+    const int npix = cw * ch;
+    const uint32_t rcp_cw = ((1u << 18) + cw - 1) / cw;          // i / cw for i < 2^12, cw <= 64
+    const int t = g.minTh;
+    int nq = 0;
+    for (int i0 = 0; i0 < npix; i0 += 64) {
+        const int i = i0 + lane;
+        bool pass = false;
+        if (i < npix) {
+            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
+            const uint8_t* c = tile8 + (py + 3) * TP + px + 3 + ox;
+            const int v = c[0], hi = v + t, lo = v - t;
+            const int p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
+            const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
+            const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
+            pass = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) ||
+                   (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
+        }
+        const unsigned long long bal = __ballot(pass);
+        if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        nq += __popcll(bal);
+    }
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < nq) {
+            const int i = s_queue[q];
+            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
+            const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
+            s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
+        }
+    }
+    __syncthreads();
+    bool any = false;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < nq) {
+            const int i = s_queue[q];
+            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
+            const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
+            const int s = sc[0];
+            if (s > 0 && s > sc[-1] && s > sc[1] && s > sc[-SP - 1] && s > sc[-SP] && s > sc[-SP + 1] &&
+                s > sc[SP - 1] && s > sc[SP] && s > sc[SP + 1]) {
+                s_queue[q] = (uint16_t)(i | 0x8000);
+                any = any || (s >= g.iniTh);
+            }
+        }
+    }
+    const bool use_ini = __ballot(any) != 0ull;
+    __syncthreads();
+    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
+    int base = 0;
+    for (int q0 = 0; q0 < nq; q0 += 64) {
+        const int q = q0 + lane;
+        bool keep = false;
+        int py = 0, px = 0, s = 0;
+        if (q < nq) {
+            const int e = s_queue[q];
+            if (e & 0x8000) {
+                const int i = e & 0x7fff;
+                py = (int)(((uint32_t)i * rcp_cw) >> 18);
+                px = i - py * cw;
+                s = s_score[(py + 1) * SP + px + 1];
+                keep = !use_ini || s >= g.iniTh;
+            }
+        }
+        const unsigned long long bal = __ballot(keep);
+        if (keep) {
+            const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+            if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+        }
+        base += __popcll(bal);
+    }
+    if (lane == 0) *count_out = min(base, L.cell_cap);
+}
+
+// ---------------------------------------------------------------------------
 // block-wide scans (blockDim.x == 256)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int wave_incl_scan(int v)
@@ -764,6 +894,28 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
         stage[p] = make_uint2(kxy[i], (uint32_t)(s_best[p] >> 32));
     }
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
+}
+
+void make_fast_lds(const FrameGeom& g, FastLds& fl)
+{
+    int wc = 1, hc = 1;
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].width > 0) { wc = std::max(wc, g.lv[l].wCell); hc = std::max(hc, g.lv[l].hCell); }
+    fl.tile_pitch = (wc + 6 + 3 + 3) & ~3;                 // + up to 3 bytes of dword misalignment
+    fl.score_pitch = (wc + 2 + 3) & ~3;
+    const int tile_bytes = fl.tile_pitch * (hc + 6);
+    const int score_bytes = fl.score_pitch * (hc + 2);
+    fl.score_off = (tile_bytes + 15) & ~15;
+    fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
+    fl.total = fl.queue_off + 2 * wc * hc + 16;
+}
+
+void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
+                            int* cell_count, int nframes, hipStream_t s)
+{
+    if (g.ncells == 0) return;
+    dim3 grid(g.ncells, nframes);
+    hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
 }
 
 size_t quadtree_lds_bytes(int max_nodes)

@@ -18,6 +18,13 @@ struct SlideMap {
     int rows[kMaxLevels];       // rows per band
 };
 
+// LDS layout of the per-cell FAST kernel, sized for the largest cell of the geometry
+struct FastLds {
+    int tile_pitch, score_pitch;   // bytes per row of the pixel tile / score tile
+    int score_off, queue_off;      // byte offsets inside the dynamic LDS block
+    int total;                     // bytes of dynamic LDS per workgroup
+};
+
 struct ScaleTab { float v[kMaxLevels]; };
 
 int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, hipStream_t s);
@@ -35,6 +42,9 @@ void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, co
                        hipStream_t s);
 void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
                        int nframes, hipStream_t s);
+void make_fast_lds(const FrameGeom& g, FastLds& fl);
+void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
+                            int* cell_count, int nframes, hipStream_t s);
 size_t quadtree_lds_bytes(int max_nodes);
 int quadtree_prepare(int max_nodes);
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,

@@ -628,6 +628,13 @@ __device__ __forceinline__ int lds_excl_scan(int* a, int n, int* tmp)
 // One workgroup per (level, frame).
 // ---------------------------------------------------------------------------
 struct QNode { short x0, x1, y0, y1; };
+// bytes of the node arrays in LDS for M nodes (the cell-offset array follows them)
+__host__ __device__ inline size_t quadtree_fixed_lds(int M_)
+{
+    const size_t M = (size_t)M_;
+    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
+}
+constexpr int kKeyRegs = 16;   // keys per thread held in registers (16 * 256 = 4096 keys per level)
 
 __device__ __forceinline__ int ceil_half(int d)
 {
@@ -639,7 +646,8 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
                                                   uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
-                                                  int* __restrict__ level_count, int* __restrict__ level_ncand)
+                                                  int* __restrict__ level_count, int* __restrict__ level_ncand,
+                                                  int off_in_lds)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int level = blockIdx.x, f = blockIdx.y;
@@ -678,8 +686,11 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
     uint8_t* kresp = key_resp + (size_t)f * g.keys_per_frame + L.key_base;
     uint16_t* knode = key_node + (size_t)f * g.keys_per_frame + L.key_base;
 
-    // ---- gather the cells' lists into one list in the reference's append order
+    // ---- gather the cells' lists into one list in the reference's append order:
+    // exclusive scan of the cell counts, then one thread per key finds its cell by
+    // binary search over the offsets (kept in LDS when they fit).
     int n;
+    int* s_off = reinterpret_cast<int*>(smem + quadtree_fixed_lds(M));    // ncell + 1 entries, if off_in_lds
     {
         const int chunk = (ncell + 255) >> 8;
         const int b = min(tid * chunk, ncell), e = min(b + chunk, ncell);
@@ -687,38 +698,87 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
         for (int c = b; c < e; c++) s += ccount[c];
         int base = block_excl_scan(s, s_tmp, &n);
         for (int c = b; c < e; c++) {
-            coff[c] = base;
+            if (off_in_lds) s_off[c] = base; else coff[c] = base;
             base += ccount[c];
         }
-        __syncthreads();
-        const int lane = tid & 63, wave = tid >> 6;
-        for (int c = wave; c < ncell; c += 4) {
-            const int cnt = ccount[c], o = coff[c];
-            const int ci = c / L.nCols, cj = c - ci * L.nCols;
-            for (int k = lane; k < cnt; k += 64) {
-                uint32_t u = cands[(size_t)c * L.cell_cap + k];
-                int x = cj * L.wCell + 3 + (int)((u >> 8) & 0xff);
-                int y = ci * L.hCell + 3 + (int)(u >> 16);
-                kxy[o + k] = (uint32_t)x | ((uint32_t)y << 16);
-                kresp[o + k] = (uint8_t)(u & 0xff);
-            }
-        }
+        if (tid == 255) { if (off_in_lds) s_off[ncell] = n; }
         __syncthreads();
     }
     if (tid == 0) level_ncand[f * kMaxLevels + level] = n;
+
+    // The first kKeyRegs*256 keys live in registers (coordinates, response and current node);
+    // only the rare overflow beyond that walks the global arrays.  FOR_KEYS(body) runs body
+    // for every key of this thread with `i` (key index), `xy` (packed coordinates) and `nd`
+    // (node word: node | quadrant << 11 | response << 16, written back afterwards).
+    uint32_t rxy[kKeyRegs], rnode[kKeyRegs];
+    auto fetch_key = [&](int i, uint32_t& xy, uint32_t& resp) {
+        int lo = 0, hi = ncell;                 // largest c with off[c] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            const int o = off_in_lds ? s_off[mid] : coff[mid];
+            if (o <= i) lo = mid; else hi = mid;
+        }
+        const int c = lo;
+        const int o = off_in_lds ? s_off[c] : coff[c];
+        const uint32_t u = cands[(size_t)c * L.cell_cap + (i - o)];
+        const int ci = c / L.nCols, cj = c - ci * L.nCols;
+        const int x = cj * L.wCell + 3 + (int)((u >> 8) & 0xff);
+        const int y = ci * L.hCell + 3 + (int)(u >> 16);
+        xy = (uint32_t)x | ((uint32_t)y << 16);
+        resp = u & 0xff;
+        kxy[i] = xy;
+        kresp[i] = (uint8_t)resp;
+    };
+#pragma unroll
+    for (int k = 0; k < kKeyRegs; k++) {
+        const int i = tid + 256 * k;
+        rxy[k] = 0u;
+        rnode[k] = 0u;
+        if (i < n) {
+            uint32_t resp;
+            fetch_key(i, rxy[k], resp);
+            rnode[k] = resp << 16;
+        }
+    }
+    for (int i = tid + 256 * kKeyRegs; i < n; i += 256) {
+        uint32_t xy, resp;
+        fetch_key(i, xy, resp);
+        knode[i] = 0;
+    }
+    __syncthreads();
+#define FOR_KEYS(...)                                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < kKeyRegs; k_++) {                   \
+        const int i = tid + 256 * k_;                                           \
+        if (i < n) {                                                            \
+            const uint32_t xy = rxy[k_];                                        \
+            uint32_t nd = rnode[k_] & 0xffffu;                                  \
+            const uint32_t resp = rnode[k_] >> 16;                              \
+            (void)xy; (void)resp;                                               \
+            __VA_ARGS__;                                                        \
+            rnode[k_] = (nd & 0xffffu) | (resp << 16);                          \
+        }                                                                       \
+    }                                                                           \
+    for (int i = tid + 256 * kKeyRegs; i < n; i += 256) {                       \
+        const uint32_t xy = kxy[i];                                             \
+        uint32_t nd = knode[i];                                                 \
+        const uint32_t resp = kresp[i];                                         \
+        (void)xy; (void)resp;                                                   \
+        __VA_ARGS__;                                                            \
+        knode[i] = (uint16_t)nd;                                                \
+    }
 
     // ---- root nodes (:492-534)
     const int nIni = L.nIni;
     const float hX = L.hX;
     for (int r = tid; r < nIni; r += 256) s_A[r] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        int x = (int)(kxy[i] & 0xffff);
+    FOR_KEYS({
+        int x = (int)(xy & 0xffff);
         int r = (int)__fdiv_rn((float)x, hX);
         r = min(max(r, 0), nIni - 1);
         atomicAdd(&s_A[r], 1);
-        knode[i] = (uint16_t)r;
-    }
+        nd = (uint32_t)r;
+    })
     __syncthreads();
     for (int r = tid; r < nIni; r += 256) s_B[r] = s_A[r] > 0;
     __syncthreads();
@@ -737,7 +797,7 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
             s_cidx[pos] = -1;
         }
     __syncthreads();
-    for (int i = tid; i < n; i += 256) knode[i] = (uint16_t)s_B[knode[i]];
+    FOR_KEYS({ nd = (uint32_t)s_B[nd]; })
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
     __syncthreads();
 
@@ -762,18 +822,17 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
         if (tid == 0) s_var[7] = 0;
         __syncthreads();
         // b. child occupancy (DivideNode :431-476)
-        for (int i = tid; i < n; i += 256) {
-            int p = knode[i] & 0x7ff;
+        FOR_KEYS({
+            int p = (int)(nd & 0x7ff);
             if (s_fl[p]) {
                 QNode q = rc[p];
-                uint32_t xy = kxy[i];
                 int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
                 int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
                 int qd = (x < q.x0 + hx ? 0 : 1) + (y < q.y0 + hy ? 0 : 2);
                 atomicAdd(&s_cc[4 * p + qd], 1);
-                knode[i] = (uint16_t)(p | (qd << 11));
+                nd = (uint32_t)(p | (qd << 11));
             }
-        }
+        })
         __syncthreads();
         // c. processing order of the parents
         int norder = lds_excl_scan(s_A, size, s_tmp);   // s_A[p] = index among flagged nodes, list order
@@ -863,11 +922,10 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
             }
         __syncthreads();
         // f. move the keys
-        for (int i = tid; i < n; i += 256) {
-            int v = knode[i];
-            int p = v & 0x7ff;
-            knode[i] = s_fl[p] ? s_childpos[4 * p + (v >> 11)] : s_newpos[p];
-        }
+        FOR_KEYS({
+            int p = (int)(nd & 0x7ff);
+            nd = s_fl[p] ? s_childpos[4 * p + (int)(nd >> 11)] : s_newpos[p];
+        })
         // g. loop control (:618-622, :683-684)
         if (tid == 0) {
             s_var[4] = newsize;
@@ -883,10 +941,11 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
     size = s_var[4];
     for (int p = tid; p < size; p += 256) s_best[p] = 0ull;
     __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        unsigned long long v = ((unsigned long long)kresp[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-        atomicMax(&s_best[knode[i]], v);
-    }
+    FOR_KEYS({
+        unsigned long long v = ((unsigned long long)resp << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
+        atomicMax(&s_best[nd & 0x7ff], v);
+    })
+#undef FOR_KEYS
     __syncthreads();
     uint2* stage = kp_stage + (size_t)f * g.kp_per_frame + L.kp_base;
     for (int p = tid; p < size && p < L.kp_cap; p += 256) {
@@ -918,12 +977,7 @@ void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLd
     hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
 }
 
-size_t quadtree_lds_bytes(int max_nodes)
-{
-    const size_t M = (size_t)max_nodes;
-    return 2 * M * sizeof(QNode) + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 +
-           2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64;
-}
+size_t quadtree_lds_bytes(int max_nodes) { return quadtree_fixed_lds(max_nodes); }
 
 // ---------------------------------------------------------------------------
 // orientation + descriptor + output assembly
@@ -1124,14 +1178,31 @@ void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_ca
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, pyr, g, cell_cand, cell_count);
 }
 
+static int max_level_cells(const FrameGeom& g)
+{
+    int m = 0;
+    for (int l = 0; l < g.nlevels; l++) m = std::max(m, g.lv[l].nCols * g.lv[l].nRows);
+    return m;
+}
+
+// dynamic LDS of the quadtree kernel; *off_in_lds says whether the cell offsets fit beside the nodes
+static size_t quadtree_total_lds(const FrameGeom& g, int* off_in_lds)
+{
+    const size_t fixed = quadtree_fixed_lds(g.max_nodes);
+    const size_t offs = ((size_t)max_level_cells(g) + 1) * 4;
+    *off_in_lds = (fixed + offs <= 64 * 1024) ? 1 : 0;
+    return *off_in_lds ? fixed + offs : fixed;
+}
+
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
                      int* level_ncand, int nframes, hipStream_t s)
 {
     dim3 grid(kMaxLevels, nframes);
-    size_t lds = quadtree_lds_bytes(g.max_nodes);
+    int off_in_lds = 0;
+    size_t lds = quadtree_total_lds(g, &off_in_lds);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand);
+                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
 }
 
 int quadtree_prepare(int max_nodes)

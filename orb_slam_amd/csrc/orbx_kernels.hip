@@ -30,10 +30,13 @@ __constant__ int8_t c_pattern[256 * 4] = {
 __constant__ int8_t c_patch_du[kPatchPixels + 3];
 __constant__ int8_t c_patch_dv[kPatchPixels + 3];
 __constant__ int c_gauss[8];
+__constant__ int c_umax[16];
 
-int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, hipStream_t s)
+int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, const int* umax16, hipStream_t s)
 {
     hipError_t e;
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int), 0, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return (int)e;
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_du), du, kPatchPixels, 0, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_dv), dv, kPatchPixels, 0, hipMemcpyHostToDevice, s);
@@ -650,7 +653,7 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
                                                   int off_in_lds)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int level = blockIdx.x, f = blockIdx.y;
+    const int level = blockIdx.y, f = blockIdx.x;   // x = frame: the large low levels are dispatched first
     const LevelGeom& L = g.lv[level];
     const int tid = threadIdx.x;
     if (level >= g.nlevels || L.width == 0) {
@@ -1043,26 +1046,40 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     const uint2 st = kp_stage[(size_t)f * g.kp_per_frame + L.kp_base + k];
     const int x = (int)(st.x & 0xffff) + kDetBorder, y = (int)(st.x >> 16) + kDetBorder;   // :1115-1116
 
-    // IC_Angle :74-101 on the un-blurred level
+    // IC_Angle :74-101 on the un-blurred level: lane = patch column u = lane-15, walking the
+    // rows |v| <= umax[|u|] of its column (the disc is symmetric in u and v); 31 independent,
+    // row-coalesced byte loads per lane, m10 = u * (column sum).
     const uint8_t* img = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
     int m10 = 0, m01 = 0;
-    for (int i = lane; i < kPatchPixels; i += 32) {
-        int du = c_patch_du[i], dv = c_patch_dv[i];
-        int val = img[dv * L.pitch + du];
-        m10 += du * val;
-        m01 += dv * val;
+    {
+        const int u = lane - kHalfPatch;
+        const int d = lane < 31 ? c_umax[u < 0 ? -u : u] : -1;
+        int colsum = 0;
+#pragma unroll
+        for (int v = -kHalfPatch; v <= kHalfPatch; v++) {
+            // unconditional load (rows +-15 of a keypoint always lie inside the plane) so that
+            // all 31 loads are in flight together; rows outside the disc contribute zero
+            const int av = v < 0 ? -v : v;
+            const int raw = img[v * L.pitch + u];
+            const int val = av <= d ? raw : 0;
+            colsum += val;
+            m01 += v * val;
+        }
+        m10 = u * colsum;
     }
 #pragma unroll
-    for (int d = 16; d >= 1; d >>= 1) {
-        m10 += __shfl_xor(m10, d, 32);
-        m01 += __shfl_xor(m01, d, 32);
+    for (int dd = 16; dd >= 1; dd >>= 1) {
+        m10 += __shfl_xor(m10, dd, 32);
+        m01 += __shfl_xor(m01, dd, 32);
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     // computeOrbDescriptor :104-150 on the blurred level; lane = descriptor byte
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float rad = __fmul_rn(angle, factorPI);
-    const float a = (float)cos((double)rad), b = (float)sin((double)rad);
+    double sn, cs;
+    sincos((double)rad, &sn, &cs);
+    const float a = (float)cs, b = (float)sn;
     const uint8_t* ctr = blur + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
     const int8_t* pat = c_pattern + lane * 32;
     int val = 0;
@@ -1198,7 +1215,7 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
                      int* level_ncand, int nframes, hipStream_t s)
 {
-    dim3 grid(kMaxLevels, nframes);
+    dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
     hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,

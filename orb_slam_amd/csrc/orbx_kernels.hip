@@ -138,20 +138,33 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
     const uint8_t* src = frame + P.plane_off + x.base;
     uint8_t* dst = frame + L.plane_off + 4 * dwc;
     const YTab2* yt = ytab + L.ytab2_off;
-    for (int r = r0; r < r1; r++) {
-        const YTab2 y = yt[r];
-        const Unaligned8 s0 = *reinterpret_cast<const Unaligned8*>(src + y.off0);
-        const Unaligned8 s1 = *reinterpret_cast<const Unaligned8*>(src + y.off1);
-        const uint32_t b0 = (uint32_t)y.b0, b1 = (uint32_t)y.b1;
-        uint32_t o = 0;
+    const int rlast = L.rows - 1;
+    // groups of 4 rows, all 8 loads issued before the arithmetic; a group that runs past the
+    // plane repeats its last row (same bytes written again)
+    for (int rg = r0; rg < r1; rg += 4) {
+        Unaligned8 s0[4], s1[4];
+        YTab2 y[4];
+        int rr[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t h0 = hpair(s0, x.sel[k], x.a01[k]);
-            const uint32_t h1 = hpair(s1, x.sel[k], x.a01[k]);
-            const uint32_t v = (((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2u) >> 2;
-            o |= (v & 0xffu) << (8 * k);
+            rr[k] = min(rg + k, rlast);
+            y[k] = yt[rr[k]];
+            s0[k] = *reinterpret_cast<const Unaligned8*>(src + y[k].off0);
+            s1[k] = *reinterpret_cast<const Unaligned8*>(src + y[k].off1);
         }
-        *reinterpret_cast<uint32_t*>(dst + (size_t)r * L.pitch) = o;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t b0 = (uint32_t)y[k].b0, b1 = (uint32_t)y[k].b1;
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t h0 = hpair(s0[k], x.sel[j], x.a01[j]);
+                const uint32_t h1 = hpair(s1[k], x.sel[j], x.a01[j]);
+                const uint32_t v = (((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2u) >> 2;
+                o |= (v & 0xffu) << (8 * j);
+            }
+            *reinterpret_cast<uint32_t*>(dst + (size_t)rr[k] * L.pitch) = o;
+        }
     }
 }
 
@@ -221,14 +234,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, u
 // 7 multiply-adds per pixel for the column, one dword store per row.
 // Work item = (level, 64-dword column block, row band); 4 items per workgroup.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void blur_hsum4(const uint8_t* p, uint32_t out[4])
+__device__ __forceinline__ void blur_hsum4w(uint32_t Lw, uint32_t Cw, uint32_t Rw, uint32_t out[4])
 {
-    // p -> 12 bytes: pixels x-4 .. x+7 of one row
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
-    const uint32_t Lw = q[0], Cw = q[1], Rw = q[2];
+    // (Lw, Cw, Rw) = 12 bytes: pixels x-4 .. x+7 of one row; pixel j's window = bytes j+1 .. j+7
     const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
     const uint32_t K1 = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
-    // pixel j: window = bytes j+1 .. j+7 of (L,C,R)
     out[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1,
                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, 0u, false), false);
     out[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1,
@@ -236,6 +246,12 @@ __device__ __forceinline__ void blur_hsum4(const uint8_t* p, uint32_t out[4])
     out[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1,
                                     __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, 0u, false), false);
     out[3] = __builtin_amdgcn_udot4(Rw, K1, __builtin_amdgcn_udot4(Cw, K0, 0u, false), false);
+}
+
+__device__ __forceinline__ void blur_hsum4(const uint8_t* p, uint32_t out[4])
+{
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+    blur_hsum4w(q[0], q[1], q[2], out);
 }
 
 __device__ __forceinline__ uint32_t blur_vsum(uint32_t h0, uint32_t h1, uint32_t h2, uint32_t h3, uint32_t h4,
@@ -266,26 +282,34 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     const uint8_t* src = pyr + fbase + (size_t)(kPadY + y0 - 3) * L.pitch + kPadX + 4 * dw - 4;
     uint8_t* dst = blur + fbase + (size_t)(kPadY + y0) * L.pitch + kPadX + 4 * dw;
     const int pitch = L.pitch;
-    const int nsteps = (y1 - y0) + 6;
 
+    // Branch-free schedule: 6 warm-up rows, then groups of 7 rows whose loads are all issued
+    // before the arithmetic.  A band's last group may run past the band (at most 6 rows): those
+    // rows are read from the stored border and written with the same values the next band
+    // writes (or into the unused border of the blurred plane).
     uint32_t h[7][4];
 #pragma unroll
-    for (int i = 0; i < 7; i++) { h[i][0] = h[i][1] = h[i][2] = h[i][3] = 0; }
-    for (int s0 = 0; s0 < nsteps; s0 += 7) {
+    for (int p = 0; p < 6; p++) blur_hsum4(src + (size_t)p * pitch, h[p]);
+    const int nrows = y1 - y0;
+    for (int r0 = 0; r0 < nrows; r0 += 7) {
+        const uint8_t* sp = src + (size_t)(r0 + 6) * pitch;
+        uint8_t* dp = dst + (size_t)r0 * pitch;
+        uint32_t raw[7][3];
 #pragma unroll
         for (int p = 0; p < 7; p++) {
-            const int s = s0 + p;
-            if (s < nsteps) {
-                blur_hsum4(src + (size_t)s * pitch, h[p]);
-                if (s >= 6) {
-                    uint32_t o = 0;
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(sp + (size_t)p * pitch);
+            raw[p][0] = q[0]; raw[p][1] = q[1]; raw[p][2] = q[2];
+        }
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        o |= blur_vsum(h[(p + 1) % 7][j], h[(p + 2) % 7][j], h[(p + 3) % 7][j], h[(p + 4) % 7][j],
-                                       h[(p + 5) % 7][j], h[(p + 6) % 7][j], h[p][j]) << (8 * j);
-                    *reinterpret_cast<uint32_t*>(dst + (size_t)(s - 6) * pitch) = o;
-                }
-            }
+        for (int p = 0; p < 7; p++) {
+            // row r0+p+6 enters slot (p+6)%7; output row r0+p uses slots (p .. p+6)%7 as taps 0..6
+            blur_hsum4w(raw[p][0], raw[p][1], raw[p][2], h[(p + 6) % 7]);
+            uint32_t o = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                o |= blur_vsum(h[p % 7][j], h[(p + 1) % 7][j], h[(p + 2) % 7][j], h[(p + 3) % 7][j],
+                               h[(p + 4) % 7][j], h[(p + 5) % 7][j], h[(p + 6) % 7][j]) << (8 * j);
+            *reinterpret_cast<uint32_t*>(dp + (size_t)p * pitch) = o;
         }
     }
 }

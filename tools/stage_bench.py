@@ -27,7 +27,9 @@ def main():
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
     d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
-    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ex.set_stream(stream.cuda_stream)
     for _ in range(3):
         ex.extract_batch_device(d_imgs, B, W, H, W, W * H, d_kps, d_desc, cap, d_n)
     torch.cuda.synchronize()

@@ -129,8 +129,6 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     const char* msg = "";
     int rc = build_geometry(c->p, w, h, g, rt, &msg);
     if (rc != ORBX_OK) return fail(c, rc, msg);
-    for (int l = 0; l < g.nlevels; l++)
-        if (g.lv[l].key_cap >= (1u << 21)) return fail(c, ORBX_ERR_UNSUPPORTED, "a level has more than 2^21 candidate slots");
     if (quadtree_prepare(g.max_nodes) != 0) return fail(c, ORBX_ERR_UNSUPPORTED, "quadtree needs more LDS than one CU has");
     HIPCHECK(c, hipStreamSynchronize(c->stream));   // old tables may still be in use
     HIPCHECK(c, c->xtab.ensure(xt.size() * sizeof(XTab)));

@@ -872,14 +872,19 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
             for (int p = tid; p < size; p += 256)
                 if (s_fl[p]) {
                     s_cand[s_A[p]] = (unsigned short)p;
-                    s_key[s_A[p]] = ((uint32_t)cc_cur[p] << 11) | (uint32_t)ci_cur[p];
+                    s_key[s_A[p]] = (uint32_t)cc_cur[p];     // size
+                    s_B[s_A[p]] = ci_cur[p];                 // creation index (distinct)
                 }
             __syncthreads();
-            // rank in (size, creation) descending order; keys are distinct
+            // rank in (size, creation) descending order
             for (int i = tid; i < m; i += 256) {
-                uint32_t ki = s_key[i];
+                const uint32_t ki = s_key[i];
+                const int ci = s_B[i];
                 int r = 0;
-                for (int j = 0; j < m; j++) r += s_key[j] > ki;
+                for (int j = 0; j < m; j++) {
+                    const uint32_t kj = s_key[j];
+                    r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                }
                 s_order[r] = s_cand[i];
             }
             __syncthreads();

@@ -164,3 +164,41 @@ def test_cpp_host_program(oracle, euroc_left, tmp_path):
     oracle.compute_pyramid(euroc_left)
     top = oracle.pyramid_plane(nl - 1)[19:-19, 19:-19]
     assert buf[-1] == top[top.shape[0] // 2, top.shape[1] // 2]
+
+
+def test_4k_8000_features():
+    """3840x2160, 8000 features: 1737-node quadtree (LDS above 64 KB), > 4096 candidates per
+    level (keys beyond the register-resident ones), 8820 cells on level 0."""
+    from orb_slam_amd import ORBextractor
+    w, h = 3840, 2160
+    img = synthetic_frame(w, h, 99, nrect=1500)
+    ex = ORBextractor(8000, 1.2, 8, 20, 7)
+    orc = Oracle(8000, 1.2, 8, 20, 7)
+    kps_g, desc_g = ex(img)
+    kps_o, desc_o = orc.extract(img, literal=True, cap=9000)
+    assert len(kps_o) > 7900
+    _assert_features(kps_g, desc_g, kps_o, desc_o)
+    assert np.array_equal(desc_g, desc_o)
+    assert np.array_equal(ex.debug_level_counts(), orc.last_level_counts())
+    orc.compute_pyramid(img)
+    for l in (0, 7):
+        assert np.array_equal(ex.pyramid_level(l, border=19), orc.pyramid_plane(l))
+        cand_o = orc.detect_level(l, literal=True)
+        cand_g = ex.debug_candidates(l)
+        assert np.array_equal(cand_g, np.stack([cand_o["x"], cand_o["y"], cand_o["response"]], 1))
+    ex.close()
+
+
+def test_small_feature_budget_and_tiny_levels():
+    """nfeatures = 40 (Tracking::updateORBExtractor re-creates extractors with small budgets):
+    N per level below 4*nIni, and a 200x150 image whose top levels are too small to search."""
+    from orb_slam_amd import ORBextractor
+    for (w, h, nf) in ((752, 480, 40), (200, 150, 300), (97, 83, 100)):
+        ex = ORBextractor(nf, 1.2, 8, 20, 7)
+        orc = Oracle(nf, 1.2, 8, 20, 7)
+        img = synthetic_frame(w, h, 5 + w, nrect=60)
+        kps_g, desc_g = ex(img)
+        kps_o, desc_o = orc.extract(img, literal=True)
+        _assert_features(kps_g, desc_g if desc_g is not None else np.zeros((0, 32), np.uint8), kps_o, desc_o)
+        assert np.array_equal(ex.debug_level_counts(), orc.last_level_counts())
+        ex.close()

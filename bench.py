@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--frames", type=int, default=256, help="frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
+                    "gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
 
 
@@ -91,18 +93,24 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=args.backend)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the timing reduction lives
 
     B = args.frames
     # synthetic frames (deterministic; every rank gets its own frames)
     host = np.stack([synthetic_frame(W, H, 1234 + rank * 100000 + i) for i in range(B)])
     d_imgs = torch.from_numpy(host).to(dev)
 
-    ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=local_rank)
+    ex = ORBextractor(NFEAT, 1.2, NLEVELS, 20, 7, device=dev_index)
     cap = ex.max_keypoints(W, H)
     d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
     d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
@@ -133,7 +141,7 @@ def main():
     t1 = time.perf_counter()
     elapsed = t1 - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stages = ex.stage_times()
@@ -211,7 +219,7 @@ def main():
             barrier()
             dt_ = time.perf_counter() - t0
             if world > 1:
-                t = torch.tensor([dt_], dtype=torch.float64, device=dev)
+                t = torch.tensor([dt_], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt_ = float(t.item())
             res[name] = {"pair_distances_per_s": round(world * pairs * reps / dt_, 1),

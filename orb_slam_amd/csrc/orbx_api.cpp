@@ -41,7 +41,7 @@ const char* kStageNames[ST_COUNT] = {"pyr_level0", "pyr_resize", "blur", "fast_c
 constexpr int kEventSets = 64;
 
 struct EventSet {
-    hipEvent_t ev[ST_COUNT + 1];
+    hipEvent_t start[ST_COUNT], stop[ST_COUNT];
     bool pending = false;
 };
 
@@ -51,6 +51,8 @@ struct orbx_ctx {
     Params p;
     int device = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t aux_stream = nullptr;   // the blur runs here, beside FAST + quadtree
+    hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
     std::string err;
 
     // geometry of the current frame size
@@ -108,10 +110,11 @@ int fail_hip(orbx_ctx* c, const char* what, hipError_t e)
 void harvest(orbx_ctx* c, EventSet& es)
 {
     if (!es.pending) return;
-    (void)hipEventSynchronize(es.ev[ST_COUNT]);
+    (void)hipEventSynchronize(es.stop[ST_DESC]);
+    (void)hipEventSynchronize(es.stop[ST_BLUR]);
     for (int s = 0; s < ST_COUNT; s++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, es.ev[s], es.ev[s + 1]) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, es.start[s], es.stop[s]) == hipSuccess) {
             c->stage_ms[s] += ms;
             c->stage_launches[s] += 1;
         }
@@ -190,16 +193,19 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         c->ev_next = (c->ev_next + 1) % kEventSets;
         harvest(c, *es);
     }
-    auto mark = [&](int i) { if (es) (void)hipEventRecord(es->ev[i], s); };
+    auto t0 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->start[i], q); };
+    auto t1 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->stop[i], q); };
 
-    mark(ST_PYR0);
+    t0(ST_PYR0, s);
     launch_pyr_level0(d_imgs, stride, frame_stride, c->pyr.as<uint8_t>(), g, nframes, s);
-    mark(ST_RESIZE);
+    t1(ST_PYR0, s);
+    t0(ST_RESIZE, s);
     const bool slide = g.resize_slide_ok && !getenv("ORBX_OLD_RESIZE");
     for (int l = 1; l < g.nlevels; l++) {
         if (slide) launch_resize_slide(c->pyr.as<uint8_t>(), g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
         else launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
     }
+    t1(ST_RESIZE, s);
     c->last_nframes = nframes;
     c->have_pyramid = true;
     c->have_features = false;
@@ -208,20 +214,35 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipGetLastError());
         return ORBX_OK;
     }
-    mark(ST_BLUR);
-    if (getenv("ORBX_OLD_BLUR")) launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, s);
-    else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, s);
-    mark(ST_FAST);
+    // The blur only feeds the descriptors, so it may run on a second stream beside FAST +
+    // quadtree (ORBX_OVERLAP=1).  Off by default: the gain is a few percent (both kernels
+    // compete for the same CUs) and per-kernel durations stop being separable.
+    static const bool want_overlap = getenv("ORBX_OVERLAP") != nullptr;
+    const bool overlap = c->aux_stream && want_overlap;
+    hipStream_t bs = overlap ? c->aux_stream : s;
+    if (overlap) {
+        HIPCHECK(c, hipEventRecord(c->ev_pyr, s));
+        HIPCHECK(c, hipStreamWaitEvent(bs, c->ev_pyr, 0));
+    }
+    t0(ST_BLUR, bs);
+    if (getenv("ORBX_OLD_BLUR")) launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, bs);
+    else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, bs);
+    t1(ST_BLUR, bs);
+    if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
+    t0(ST_FAST, s);
     if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
     else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
-    mark(ST_QUADTREE);
+    t1(ST_FAST, s);
+    t0(ST_QUADTREE, s);
     launch_quadtree(g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), c->cell_off.as<int>(),
                     c->key_xy.as<uint32_t>(), c->key_resp.as<uint8_t>(), c->key_node.as<uint16_t>(), c->kp_stage.p,
                     c->level_count.as<int>(), c->level_ncand.as<int>(), nframes, s);
-    mark(ST_DESC);
+    t1(ST_QUADTREE, s);
+    if (overlap) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_blur, 0));
+    t0(ST_DESC, s);
     launch_orient_desc(g, c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), c->kp_stage.p, c->level_count.as<int>(),
                        d_kps, d_desc, cap, d_n_out, nframes, s);
-    mark(ST_COUNT);
+    t1(ST_DESC, s);
     if (es) es->pending = true;
     HIPCHECK(c, hipGetLastError());
     c->have_features = true;
@@ -273,8 +294,15 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scaleFactor, int nlevels, i
     }
     c->events_ok = true;
     for (int i = 0; i < kEventSets && c->events_ok; i++)
-        for (int j = 0; j <= ST_COUNT; j++)
-            if (hipEventCreate(&c->evs[i].ev[j]) != hipSuccess) { c->events_ok = false; break; }
+        for (int j = 0; j < ST_COUNT; j++)
+            if (hipEventCreate(&c->evs[i].start[j]) != hipSuccess || hipEventCreate(&c->evs[i].stop[j]) != hipSuccess) {
+                c->events_ok = false;
+                break;
+            }
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pyr, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_blur, hipEventDisableTiming) != hipSuccess)
+        c->aux_stream = nullptr;   // no overlap, still correct
     *out = c;
     return ORBX_OK;
 }
@@ -289,9 +317,13 @@ void orbx_destroy(orbx_ctx* c)
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9};
     for (DevBuf* b : bufs) b->release();
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->events_ok)
         for (int i = 0; i < kEventSets; i++)
-            for (int j = 0; j <= ST_COUNT; j++) (void)hipEventDestroy(c->evs[i].ev[j]);
+            for (int j = 0; j < ST_COUNT; j++) { (void)hipEventDestroy(c->evs[i].start[j]); (void)hipEventDestroy(c->evs[i].stop[j]); }
+    if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
+    if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
+    if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }

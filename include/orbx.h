@@ -177,6 +177,23 @@ int orbx_stereo_match_device(orbx_ctx *ctx, const orbx_keypoint *d_kl, const uin
                              int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
                              int32_t *d_nmatched);
 
+/* Classic stereo matching with sub-pixel refinement: Frame::ComputeStereoMatches,
+ * src/Frame.cc:984-1173 -- row-band Hamming search, 11x11 SAD sliding window on pyramid level
+ * kpL.octave of the left and right extractors' pyramids (mvImagePyramid, :1089,:1111), parabola
+ * fit, disparity gating, cut at 2.1 x the median SAD.  `left` and `right` are the two extractor
+ * contexts (same device, same parameters, same frame size) whose last extract call produced the
+ * keypoints; pair b uses frame b of both.  Work runs on left's stream after right's stream.
+ * Host variant: one pair (frame 0 of both contexts). */
+int orbx_stereo_match_sad(orbx_ctx *left, orbx_ctx *right, const orbx_keypoint *kl, const uint32_t *dl, int nl,
+                          const orbx_keypoint *kr, const uint32_t *dr, int nr, float mbf, float mb,
+                          int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth, int *nmatched);
+int orbx_stereo_match_sad_device(orbx_ctx *left, orbx_ctx *right,
+                                 const orbx_keypoint *d_kl, const uint32_t *d_dl, const int32_t *d_nl,
+                                 const orbx_keypoint *d_kr, const uint32_t *d_dr, const int32_t *d_nr,
+                                 int nbatch, int stride, float mbf, float mb,
+                                 int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
+                                 int32_t *d_nmatched);
+
 #ifdef __cplusplus
 }
 #endif

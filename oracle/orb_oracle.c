@@ -1240,3 +1240,124 @@ int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
     free(v);
     return nmatched;
 }
+
+/* src/Frame.cc:984-1173 */
+int oo_stereo_classic(const oo_extractor *exl, const oo_extractor *exr,
+                      const oo_keypoint *kl, const uint32_t *dl, int nl,
+                      const oo_keypoint *kr, const uint32_t *dr, int nr,
+                      float mbf, float mb,
+                      int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth)
+{
+    const int B = OO_EDGE_THRESHOLD;
+    const int thOrbDist = (100 + 50) / 2;
+    const int nRows = exl->lh[0];
+    int *cnt = (int *)calloc((size_t)nRows + 1, sizeof(int));
+    for (int pass = 0; pass < 1; pass++)
+        for (int iR = 0; iR < nr; iR++) {
+            const float kpY = kr[iR].y;
+            const float r = 2.0f * exl->scale[kr[iR].octave];
+            int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+            if (minr < 0) minr = 0;
+            if (maxr > nRows - 1) maxr = nRows - 1;
+            for (int yi = minr; yi <= maxr; yi++) cnt[yi + 1]++;
+        }
+    for (int y = 0; y < nRows; y++) cnt[y + 1] += cnt[y];
+    int *fill = (int *)malloc(sizeof(int) * ((size_t)nRows + 1));
+    memcpy(fill, cnt, sizeof(int) * ((size_t)nRows + 1));
+    int *rowidx = (int *)malloc(sizeof(int) * (cnt[nRows] > 0 ? cnt[nRows] : 1));
+    for (int iR = 0; iR < nr; iR++) {
+        const float kpY = kr[iR].y;
+        const float r = 2.0f * exl->scale[kr[iR].octave];
+        int maxr = (int)ceilf(kpY + r), minr = (int)floorf(kpY - r);
+        if (minr < 0) minr = 0;
+        if (maxr > nRows - 1) maxr = nRows - 1;
+        for (int yi = minr; yi <= maxr; yi++) rowidx[fill[yi]++] = iR;
+    }
+    const float minZ = mb, minD = 0, maxD = mbf / minZ;
+    distidx *v = (distidx *)malloc(sizeof(distidx) * (nl > 0 ? nl : 1));
+    int nv = 0;
+    for (int iL = 0; iL < nl; iL++) {
+        best_idx[iL] = -1;
+        best_dist[iL] = 100;
+        u_right[iL] = -1.0f;
+        depth[iL] = -1.0f;
+        const int levelL = kl[iL].octave;
+        const float vL = kl[iL].y, uL = kl[iL].x;
+        int row = (int)vL;
+        if (row < 0 || row >= nRows) continue;
+        if (cnt[row + 1] == cnt[row]) continue;
+        const float minU = uL - maxD, maxU = uL - minD;
+        if (maxU < 0) continue;
+        int bestDist = 100, bestIdxR = 0;
+        for (int k = cnt[row]; k < cnt[row + 1]; k++) {
+            int iR = rowidx[k];
+            if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+            const float uR = kr[iR].x;
+            if (uR >= minU && uR <= maxU) {
+                int dist = oo_hamming(dl + 8 * (size_t)iL, dr + 8 * (size_t)iR);
+                if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+            }
+        }
+        best_idx[iL] = bestIdxR;
+        best_dist[iL] = bestDist;
+        if (bestDist < thOrbDist) {
+            /* coordinates in the image pyramid at the left keypoint's scale (:1076-1081) */
+            const float uR0 = kr[bestIdxR].x;
+            const float scaleFactor = exl->inv_scale[levelL];
+            const float scaleduL = roundf(kl[iL].x * scaleFactor);
+            const float scaledvL = roundf(kl[iL].y * scaleFactor);
+            const float scaleduR0 = roundf(uR0 * scaleFactor);
+            const int w = 5, L = 5;
+            const int pitchL = exl->lw[levelL] + 2 * B, pitchR = exr->lw[levelL] + 2 * B;
+            const uint8_t *imL = exl->plane[levelL] + (size_t)B * pitchL + B;
+            const uint8_t *imR = exr->plane[levelL] + (size_t)B * pitchR + B;
+            const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+            const float iniu = scaleduR0 + L - w, endu = scaleduR0 + L + w + 1;
+            if (iniu < 0 || endu >= exr->lw[levelL]) continue;
+            int bestDistS = 2147483647, bestincR = 0;
+            float vDists[11];
+            const float cL = (float)imL[(ptrdiff_t)cy * pitchL + cxL];
+            for (int incR = -L; incR <= L; incR++) {
+                const float cR = (float)imR[(ptrdiff_t)cy * pitchR + cxR0 + incR];
+                float dist = 0;
+                for (int dy = -w; dy <= w; dy++)
+                    for (int dx = -w; dx <= w; dx++) {
+                        float a = (float)imL[(ptrdiff_t)(cy + dy) * pitchL + cxL + dx] - cL;
+                        float b = (float)imR[(ptrdiff_t)(cy + dy) * pitchR + cxR0 + incR + dx] - cR;
+                        dist += fabsf(a - b);
+                    }
+                if (dist < (float)bestDistS) { bestDistS = (int)dist; bestincR = incR; }
+                vDists[L + incR] = dist;
+            }
+            if (bestincR == -L || bestincR == L) continue;
+            const float dist1 = vDists[L + bestincR - 1], dist2 = vDists[L + bestincR], dist3 = vDists[L + bestincR + 1];
+            const float deltaR = (dist1 - dist3) / (2.0f * (dist1 + dist3 - 2.0f * dist2));
+            if (deltaR < -1 || deltaR > 1) continue;
+            float bestuR = exl->scale[levelL] * ((float)scaleduR0 + (float)bestincR + deltaR);
+            float disparity = (uL - bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = (float)(uL - 0.01);
+                }
+                depth[iL] = mbf / disparity;
+                u_right[iL] = bestuR;
+                v[nv].dist = bestDistS; v[nv].idx = iL; nv++;
+            }
+        }
+    }
+    int nkept = nv;
+    if (nv > 0) {
+        qsort(v, nv, sizeof(distidx), distidx_cmp);
+        const float median = (float)v[nv / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; i--) {
+            if ((float)v[i].dist < thDist) break;
+            u_right[v[i].idx] = -1;
+            depth[v[i].idx] = -1;
+            nkept--;
+        }
+    }
+    free(v); free(cnt); free(fill); free(rowidx);
+    return nkept;
+}

@@ -140,6 +140,19 @@ int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
                      const int32_t *best_idx, const int32_t *best_dist,
                      float mbf, float minD, float maxD, float *u_right, float *depth);
 
+/* Frame::ComputeStereoMatches, src/Frame.cc:984-1173 (the classic variant): row-band Hamming
+ * search, then 11x11 SAD sliding-window refinement on pyramid level kpL.octave of the two
+ * extractors' last pyramids, parabola sub-pixel fit, disparity gating, and the median cut on the
+ * SAD distances.  The reference indexes its row table without clamping (:1007-1011); rows are
+ * clamped to [0, nRows-1] here (no effect on keypoints the extractor produces).
+ * best_idx/best_dist: result of the Hamming scan (best_idx = -1 if the left keypoint was skipped);
+ * u_right/depth: -1 where no stereo match survives. Returns the number of surviving matches. */
+int oo_stereo_classic(const oo_extractor *exl, const oo_extractor *exr,
+                      const oo_keypoint *kl, const uint32_t *dl, int nl,
+                      const oo_keypoint *kr, const uint32_t *dr, int nr,
+                      float mbf, float mb,
+                      int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,9 @@ SIGNATURES = {
     "orbx_match_windowed": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_hamming_csr": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _ip]),
+    "orbx_stereo_match_sad": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _ip]),
+    "orbx_stereo_match_sad_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
+                                          _vp, _vp, _vp, _vp, _vp]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp]),
 }

@@ -768,4 +768,86 @@ int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, 
     return ORBX_OK;
 }
 
+int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* d_kl, const uint32_t* d_dl,
+                                 const int32_t* d_nl, const orbx_keypoint* d_kr, const uint32_t* d_dr,
+                                 const int32_t* d_nr, int nbatch, int stride, float mbf, float mb, int32_t* d_best_idx,
+                                 int32_t* d_best_dist, float* d_u_right, float* d_depth, int32_t* d_nmatched)
+{
+    if (!c || !r) return ORBX_ERR_INVALID;
+    if (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist || !d_u_right || !d_depth || !d_nmatched)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (nbatch < 1 || stride < 1) return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per image");
+    if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
+    if (c->device != r->device) return fail(c, ORBX_ERR_INVALID, "left and right contexts are on different devices");
+    if (!c->have_pyramid || !r->have_pyramid) return fail(c, ORBX_ERR_STATE, "both contexts need a computed pyramid");
+    if (c->gw != r->gw || c->gh != r->gh || c->p.nlevels != r->p.nlevels || c->p.scaleFactor != r->p.scaleFactor)
+        return fail(c, ORBX_ERR_INVALID, "left and right contexts differ in frame size or pyramid parameters");
+    if (nbatch > c->last_nframes || nbatch > r->last_nframes) return fail(c, ORBX_ERR_INVALID, "more pairs than frames in the pyramids");
+    if (c->g.lv[0].h > 32767) return fail(c, ORBX_ERR_UNSUPPORTED, "image taller than 32767 rows");
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (r->stream != c->stream) {   // the right pyramid must be complete before the left stream reads it
+        if (!c->ev_pyr) return fail(c, ORBX_ERR_HIP, "no event available");
+        HIPCHECK(c, hipEventRecord(c->ev_pyr, r->stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_pyr, 0));
+    }
+    launch_stereo_classic(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, c->pyr.as<uint8_t>(), r->pyr.as<uint8_t>(),
+                          c->g, c->p.scale, c->p.inv_scale, mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth,
+                          d_nmatched, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_stereo_match_sad(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* kl, const uint32_t* dl, int nl,
+                          const orbx_keypoint* kr, const uint32_t* dr, int nr, float mbf, float mb, int32_t* best_idx,
+                          int32_t* best_dist, float* u_right, float* depth, int* nmatched)
+{
+    if (!c || !r || !nmatched) return ORBX_ERR_INVALID;
+    *nmatched = 0;
+    if (nl < 0 || nr < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (nl == 0) return ORBX_OK;
+    if (!kl || !dl || !best_idx || !best_dist || !u_right || !depth || (nr > 0 && (!kr || !dr)))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < nr; i++)
+        if (kr[i].octave < 0 || kr[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "right keypoint octave out of range");
+    for (int i = 0; i < nl; i++)
+        if (kl[i].octave < 0 || kl[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "left keypoint octave out of range");
+    const int stride = nl > nr ? nl : nr;
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, hipStreamSynchronize(r->stream));
+    const size_t S = (size_t)stride;
+    HIPCHECK(c, c->m0.ensure(S * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->m1.ensure(S * 32));
+    HIPCHECK(c, c->m2.ensure(S * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->m3.ensure(S * 32));
+    HIPCHECK(c, c->m4.ensure(16));
+    HIPCHECK(c, c->m5.ensure(S * 4));
+    HIPCHECK(c, c->m6.ensure(S * 4));
+    HIPCHECK(c, c->m7.ensure(S * 4));
+    HIPCHECK(c, c->m8.ensure(S * 4));
+    int32_t counts[3] = {nl, nr, 0};
+    HIPCHECK(c, hipMemcpyAsync(c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->m1.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, c->stream));
+    if (nr > 0) {
+        HIPCHECK(c, hipMemcpyAsync(c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, hipMemcpyAsync(c->m3.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, c->stream));
+    }
+    HIPCHECK(c, hipMemcpyAsync(c->m4.p, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+    int rc = orbx_stereo_match_sad_device(c, r, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
+                                          c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1,
+                                          stride, mbf, mb, c->m5.as<int32_t>(), c->m6.as<int32_t>(), c->m7.as<float>(),
+                                          c->m8.as<float>(), c->m4.as<int32_t>() + 2);
+    if (rc != ORBX_OK) return rc;
+    int32_t nm = 0;
+    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m5.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m6.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(u_right, c->m7.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(depth, c->m8.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(&nm, c->m4.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    *nmatched = nm;
+    return ORBX_OK;
+}
+
 } // extern "C"

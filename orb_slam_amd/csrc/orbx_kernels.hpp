@@ -71,4 +71,11 @@ void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const 
                          int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
                          int32_t* d_nmatched, hipStream_t s);
 
+void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                           const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
+                           int nbatch, int stride, const uint8_t* pyrL, const uint8_t* pyrR, const FrameGeom& g,
+                           const float* scale8, const float* inv_scale8, float mbf, float mb,
+                           int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
+                           int32_t* d_nmatched, hipStream_t s);
+
 } // namespace orbx

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __res
                                                       ScaleTab sc, float mbf, float mb, float min_x,
                                                       int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
                                                       float* __restrict__ u_right, float* __restrict__ depth,
-                                                      int32_t* __restrict__ nmatched)
+                                                      int32_t* __restrict__ nmatched, int classic)
 {
     __shared__ short s_minr[kStereoMaxRight], s_maxr[kStereoMaxRight];
     __shared__ float s_ur[kStereoMaxRight];
@@ -255,8 +255,9 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __res
         float ur = -1.0f, dp = -1.0f;
         const float vL = k.y, uL = k.x;
         const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
-        if (!(vL < 0 || vL > (float)(nrows - 1)) && !(maxU < min_x)) {
-            const int row = (int)vL;
+        const int row = (int)vL;
+        const bool row_ok = classic ? (row >= 0 && row < nrows) : !(vL < 0 || vL > (float)(nrows - 1));
+        if (row_ok && !(maxU < min_x)) {
             uint32_t qd[8];
             const uint4* qp = reinterpret_cast<const uint4*>(dl + (size_t)iL * 8);
             uint4 a = qp[0], c = qp[1];
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __res
             if (any) {
                 bidx = bestIdxR;
                 my_matched++;
-                if (bdist < thOrbDist) {
+                if (!classic && bdist < thOrbDist) {
                     float bestuR = s_ur[bestIdxR];
                     float disparity = __fsub_rn(uL, bestuR);
                     if (disparity >= minD && disparity < maxD) {
@@ -334,7 +335,139 @@ __global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __res
     }
     if (removed) atomicSub(&s_nmatched, removed);
     __syncthreads();
-    if (tid == 0) nmatched[b] = s_nmatched;
+    if (tid == 0 && !classic) nmatched[b] = s_nmatched;
+}
+
+// ---------------------------------------------------------------------------
+// Classic stereo refinement, Frame::ComputeStereoMatches src/Frame.cc:1070-1172:
+// for every left keypoint whose Hamming match is below 75, an 11x11 SAD window
+// (each patch minus its centre pixel) slides +-5 px over the right pyramid
+// level kpL.octave; parabola sub-pixel fit, disparity gating, then the cut at
+// 2.1 x the median SAD.  One workgroup per stereo pair; one wavefront per
+// accepted keypoint at a time: work item (row dy, shift incR) sums |a-b| over the
+// 11 columns, 11 lanes then add the rows.  All sums are exact integers.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restrict__ kl, const int32_t* __restrict__ nl_arr,
+                                                    const orbx_keypoint* __restrict__ kr, int stride,
+                                                    const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR,
+                                                    FrameGeom g, ScaleTab sc, ScaleTab inv_sc, float mbf, float mb,
+                                                    const int32_t* __restrict__ best_idx, const int32_t* __restrict__ best_dist,
+                                                    float* __restrict__ u_right, float* __restrict__ depth,
+                                                    int32_t* __restrict__ nmatched)
+{
+    __shared__ unsigned short s_list[kStereoMaxRight];      // left keypoints with a Hamming match < 75
+    __shared__ int s_sad[kStereoMaxRight];                  // accepted: best SAD
+    __shared__ unsigned short s_acc[kStereoMaxRight];       // accepted: left index
+    __shared__ int s_part[4][128];
+    __shared__ int s_nlist, s_nacc, s_median;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = min(nl_arr[b], min(stride, kStereoMaxRight));
+    kl += (size_t)b * stride; kr += (size_t)b * stride;
+    best_idx += (size_t)b * stride; best_dist += (size_t)b * stride;
+    u_right += (size_t)b * stride; depth += (size_t)b * stride;
+    pyrL += (size_t)b * g.pyr_frame_bytes; pyrR += (size_t)b * g.pyr_frame_bytes;
+    if (tid == 0) { s_nlist = 0; s_nacc = 0; }
+    __syncthreads();
+    for (int iL = tid; iL < nl; iL += 256)
+        if (best_idx[iL] >= 0 && best_dist[iL] < 75) s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)iL;
+    __syncthreads();
+    const int nlist = s_nlist;
+    const float minD = 0.0f, maxD = __fdiv_rn(mbf, mb);
+    for (int e = wave; e < nlist; e += 4) {
+        const int iL = s_list[e];
+        const orbx_keypoint kpL = kl[iL];
+        const int lvl = min(max(kpL.octave, 0), g.nlevels - 1);
+        const LevelGeom& L = g.lv[lvl];
+        const float uR0 = kr[best_idx[iL]].x;
+        const float sf = inv_sc.v[lvl];
+        const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
+        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+        const float endu = __fadd_rn(scaleduR0, 11.0f);
+        bool ok = !(scaleduR0 < 0.0f || endu >= (float)L.w);
+        const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+        // keep every access inside the stored plane even for keypoints the extractor would never produce
+        ok = ok && cy >= 5 - kPadY && cy < L.h + kPadY - 5 && cxL >= 5 - kPadX && cxL < L.w + kPadX - 5 &&
+             cxR0 >= 10 - kPadX && cxR0 < L.w + kPadX - 10;
+        if (ok) {
+            const uint8_t* imL = pyrL + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxL;
+            const uint8_t* imR = pyrR + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxR0;
+            const int cL = imL[0];
+            for (int it = lane; it < 121; it += 64) {
+                const int dy = it / 11 - 5, inc = it % 11 - 5;
+                const int cR = imR[inc];
+                const uint8_t* pl = imL + dy * L.pitch;
+                const uint8_t* pr = imR + dy * L.pitch + inc;
+                int acc = 0;
+#pragma unroll
+                for (int dx = -5; dx <= 5; dx++) acc += abs(((int)pl[dx] - cL) - ((int)pr[dx] - cR));
+                s_part[wave][it] = acc;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int dist = 0x7fffffff;
+        if (ok && lane < 11) {
+            dist = 0;
+            for (int r = 0; r < 11; r++) dist += s_part[wave][r * 11 + lane];
+        }
+        // first minimum over the 11 shifts (strict '<' in the reference: lowest incR wins ties)
+        int key = (lane < 11 && ok) ? ((dist << 4) | lane) : 0x7fffffff;
+        int kmin = key;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, __shfl_xor(kmin, d, 16));
+        const int bestSlot = kmin & 15, bestSad = kmin >> 4;
+        const float d1 = (float)__shfl(dist, max(bestSlot - 1, 0), 64);
+        const float d2 = (float)__shfl(dist, bestSlot, 64);
+        const float d3 = (float)__shfl(dist, min(bestSlot + 1, 10), 64);
+        if (lane == 0 && ok && bestSlot != 0 && bestSlot != 10) {
+            const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
+                                           __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+            if (!(deltaR < -1.0f || deltaR > 1.0f)) {
+                float bestuR = __fmul_rn(sc.v[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)(bestSlot - 5)), deltaR));
+                float disparity = __fsub_rn(kpL.x, bestuR);
+                if (disparity >= minD && disparity < maxD) {
+                    if (disparity <= 0) {
+                        disparity = 0.01f;
+                        bestuR = (float)((double)kpL.x - 0.01);
+                    }
+                    depth[iL] = __fdiv_rn(mbf, disparity);
+                    u_right[iL] = bestuR;
+                    const int slot = atomicAdd(&s_nacc, 1);
+                    s_sad[slot] = bestSad;
+                    s_acc[slot] = (unsigned short)iL;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // median = element nacc/2 of the list sorted by (SAD, left index), :1159-1160
+    const int nacc = s_nacc;
+    if (tid == 0) s_median = -1;
+    __syncthreads();
+    for (int i = tid; i < nacc; i += 256) {
+        const int di = s_sad[i], ii = s_acc[i];
+        int rank = 0;
+        for (int j = 0; j < nacc; j++) {
+            const int dj = s_sad[j];
+            rank += (dj < di) || (dj == di && s_acc[j] < ii);
+        }
+        if (rank == nacc / 2) s_median = di;
+    }
+    __syncthreads();
+    int removed = 0;
+    if (nacc > 0) {
+        const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
+        for (int i = tid; i < nacc; i += 256)
+            if (!((float)s_sad[i] < thDist)) {
+                u_right[s_acc[i]] = -1.0f;
+                depth[s_acc[i]] = -1.0f;
+                removed++;
+            }
+    }
+    if (removed) atomicSub(&s_nacc, removed);
+    __syncthreads();
+    if (tid == 0) nmatched[b] = s_nacc;
 }
 
 void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
@@ -346,7 +479,23 @@ void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const 
     ScaleTab sc;
     for (int i = 0; i < kMaxLevels; i++) sc.v[i] = scale8[i];
     hipLaunchKernelGGL(k_stereo_match, dim3(nbatch), dim3(256), 0, s, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, stride,
-                       nrows, sc, mbf, mb, min_x, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
+                       nrows, sc, mbf, mb, min_x, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, 0);
+}
+
+void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                           const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
+                           int nbatch, int stride, const uint8_t* pyrL, const uint8_t* pyrR, const FrameGeom& g,
+                           const float* scale8, const float* inv_scale8, float mbf, float mb,
+                           int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
+                           int32_t* d_nmatched, hipStream_t s)
+{
+    ScaleTab sc, isc;
+    for (int i = 0; i < kMaxLevels; i++) { sc.v[i] = scale8[i]; isc.v[i] = inv_scale8[i]; }
+    const int nrows = g.lv[0].h;
+    hipLaunchKernelGGL(k_stereo_match, dim3(nbatch), dim3(256), 0, s, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, stride,
+                       nrows, sc, mbf, mb, 0.0f, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, 1);
+    hipLaunchKernelGGL(k_stereo_sad, dim3(nbatch), dim3(256), 0, s, d_kl, d_nl, d_kr, stride, pyrL, pyrR, g, sc, isc,
+                       mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
 }
 
 } // namespace orbx

@@ -93,3 +93,28 @@ class ORBmatcher:
         check(self._lib, self._ctx, self._lib.orbx_stereo_match_device(
             self._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr), nbatch, stride, nrows,
             mbf, mb, min_x, ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))
+
+    def stereo_match_sad(self, right_extractor, kl, dl, kr, dr, mbf, mb):
+        """Frame::ComputeStereoMatches (src/Frame.cc:984-1173): Hamming row-band search + SAD
+        sub-pixel refinement on the pyramids of this matcher's extractor (left) and
+        `right_extractor`, which must hold the frames the keypoints came from."""
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        dl, dr = _desc(dl), _desc(dr)
+        nl, nr = len(kl), len(kr)
+        bi = np.zeros(max(nl, 1), np.int32)
+        bd = np.zeros(max(nl, 1), np.int32)
+        ur = np.zeros(max(nl, 1), np.float32)
+        dp = np.zeros(max(nl, 1), np.float32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match_sad(
+            self._ctx, right_extractor._ctx, kl.ctypes.data, dl.ctypes.data, nl, kr.ctypes.data if nr else None,
+            dr.ctypes.data if nr else None, nr, mbf, mb,
+            bi.ctypes.data, bd.ctypes.data, ur.ctypes.data, dp.ctypes.data, C.byref(nm)))
+        return bi[:nl], bd[:nl], ur[:nl], dp[:nl], nm.value
+
+    def stereo_match_sad_device(self, right_extractor, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, mbf, mb,
+                                d_bi, d_bd, d_ur, d_dp, d_nm):
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match_sad_device(
+            self._ctx, right_extractor._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr),
+            nbatch, stride, mbf, mb, ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))

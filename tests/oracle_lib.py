@@ -69,6 +69,8 @@ class Oracle:
                                          C.c_int, C.c_float, C.c_float, C.c_float, _i32p, _i32p]
         lib.oo_stereo_finish.argtypes = [C.c_void_p, C.c_int, C.c_void_p, _i32p, _i32p,
                                          C.c_float, C.c_float, C.c_float, _f32p, _f32p]
+        lib.oo_stereo_classic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int,
+                                          C.c_float, C.c_float, _i32p, _i32p, _f32p, _f32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -263,3 +265,17 @@ class Oracle:
         n = self.lib.oo_stereo_finish(kl.ctypes.data, len(kl), kr.ctypes.data, _ptr(bi, _i32p), _ptr(bd, _i32p),
                                       mbf, minD, maxD, _ptr(ur, _f32p), _ptr(dp, _f32p))
         return n, ur[:len(kl)], dp[:len(kl)]
+
+    def stereo_classic(self, right_oracle, kl, dl, kr, dr, mbf, mb):
+        """self / right_oracle hold the pyramids of the left / right frame"""
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+        dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        n = max(len(kl), 1)
+        bi, bd = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        ur, dp = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        nm = self.lib.oo_stereo_classic(self.h, right_oracle.h, kl.ctypes.data, _ptr(dl.view(np.uint32), _u32p), len(kl),
+                                        kr.ctypes.data, _ptr(dr.view(np.uint32), _u32p), len(kr), mbf, mb,
+                                        _ptr(bi, _i32p), _ptr(bd, _i32p), _ptr(ur, _f32p), _ptr(dp, _f32p))
+        return bi[:len(kl)], bd[:len(kl)], ur[:len(kl)], dp[:len(kl)], nm

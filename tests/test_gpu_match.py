@@ -155,3 +155,26 @@ def test_stereo_edge_cases(ex, matcher, oracle):
     # no right keypoints at all
     bi, bd, ur, dp, nm = matcher.stereo_match(kl, dl, kr[:0], dr[:0], 480, mbf, mb, 0.0)
     assert (bi == -1).all() and (ur == -1).all() and nm == 0
+
+
+def test_stereo_classic_sad_refinement(ex, matcher):
+    """Frame::ComputeStereoMatches with the SAD sub-pixel refinement on both extractors' pyramids."""
+    from orb_slam_amd import ORBextractor
+    from oracle_lib import Oracle
+    exr = ORBextractor(1000, 1.2, 8, 20, 7)
+    ol, orr = Oracle(1000, 1.2, 8, 20, 7), Oracle(1000, 1.2, 8, 20, 7)
+    for seed in (4321, 77):
+        left, right = synthetic_stereo_pair(752, 480, seed)
+        kl, dl = ex(left)
+        kr, dr = exr(right)
+        kl_o, dl_o = ol.extract(left)
+        kr_o, dr_o = orr.extract(right)
+        assert np.array_equal(kl, kl_o) and np.array_equal(kr, kr_o)
+        mbf, mb = 47.9, 0.11
+        bi, bd, ur, dp, nm = matcher.stereo_match_sad(exr, kl, dl, kr, dr, mbf, mb)
+        oi, od, our, odp, onm = ol.stereo_classic(orr, kl, dl, kr, dr, mbf, mb)
+        assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+        assert nm == onm
+        assert np.array_equal(ur, our) and np.array_equal(dp, odp)       # float results bit-identical
+        assert (ur >= 0).sum() > 100
+    exr.close()

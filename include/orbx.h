@@ -194,6 +194,43 @@ int orbx_stereo_match_sad_device(orbx_ctx *left, orbx_ctx *right,
                                  int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
                                  int32_t *d_nmatched);
 
+/* --- frame grid: candidate generation for the windowed searches ------------------------ */
+/* Frame::AssignFeaturesToGrid / PosInGrid (src/Frame.cc:536-551, :724-734) and
+ * Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) (:669-722) on the reference's 64 x 48
+ * grid (include/Frame.h:92-93).  kps: the frame's (undistorted) keypoints; min_x/min_y =
+ * mnMinX/mnMinY, inv_w/inv_h = mfGridElementWidthInv/HeightInv (src/Frame.cc:134-135).
+ * Query q asks for the keypoints within the square of half-size qr[q] around (qx[q], qy[q])
+ * with octave in [qmin[q], qmax[q]] under the reference's level rules.
+ *
+ * orbx_features_in_area: the candidate lists themselves, CSR (cand_off[Q+1], cand_idx[cap]),
+ * each in the reference's order (cell columns, cell rows, ascending keypoint index).
+ * *total = number of candidates; ORBX_ERR_CAPACITY if cap is smaller (cand_off is still valid). */
+int orbx_features_in_area(orbx_ctx *ctx, const orbx_keypoint *kps, int N,
+                          float min_x, float min_y, float inv_w, float inv_h,
+                          const float *qx, const float *qy, const float *qr,
+                          const int32_t *qmin, const int32_t *qmax, int Q,
+                          int32_t *cand_off, int32_t *cand_idx, int cap, int *total);
+/* orbx_grid_search: GetFeaturesInArea fused with the best / second-best scan of
+ * src/ORBmatcher.cc:186-225 -- the result orbx_match_windowed gives on those lists, without
+ * materialising them.  qdesc: Q query descriptors; desc: the frame's descriptors.
+ * ncand (may be NULL): number of candidates per query. Host buffers, one frame. */
+int orbx_grid_search(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, int N,
+                     float min_x, float min_y, float inv_w, float inv_h,
+                     const float *qx, const float *qy, const float *qr,
+                     const int32_t *qmin, const int32_t *qmax, const uint32_t *qdesc, int Q,
+                     int32_t *best_idx, int32_t *best_dist, int32_t *second_dist,
+                     int32_t *best_lvl, int32_t *second_lvl, int32_t *ncand);
+/* Device-resident, asynchronous, batched over frames: frame b reads d_kps + b*stride
+ * (d_n[b] keypoints, or N if d_n == NULL) and its queries at offset b*q_stride (d_nq[b] of them,
+ * or Q).  Outputs are [nbatch][q_stride].  Feeds directly on orbx_extract_batch_device output. */
+int orbx_grid_search_device(orbx_ctx *ctx, const orbx_keypoint *d_kps, const uint32_t *d_desc, const int32_t *d_n,
+                            int N, int stride, int nbatch, float min_x, float min_y, float inv_w, float inv_h,
+                            const float *d_qx, const float *d_qy, const float *d_qr,
+                            const int32_t *d_qmin, const int32_t *d_qmax, const uint32_t *d_qdesc,
+                            const int32_t *d_nq, int Q, int q_stride,
+                            int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist,
+                            int32_t *d_best_lvl, int32_t *d_second_lvl, int32_t *d_ncand);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1361,3 +1361,64 @@ int oo_stereo_classic(const oo_extractor *exl, const oo_extractor *exr,
     free(v); free(cnt); free(fill); free(rowidx);
     return nkept;
 }
+
+/* src/Frame.cc:536-551, :669-734 */
+#define OO_GRID_COLS 64
+#define OO_GRID_ROWS 48
+int oo_features_in_area(const oo_keypoint *kps, int n, float minX, float minY, float invW, float invH,
+                        const float *qx, const float *qy, const float *qr, const int32_t *qmin,
+                        const int32_t *qmax, int Q, int32_t *cand_off, int32_t *cand_idx, int cap)
+{
+    /* mGrid[col][row] as CSR, keypoints pushed in index order */
+    int *start = (int *)calloc(OO_GRID_COLS * OO_GRID_ROWS + 1, sizeof(int));
+    int *cellof = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        int posX = (int)roundf((kps[i].x - minX) * invW);
+        int posY = (int)roundf((kps[i].y - minY) * invH);
+        cellof[i] = -1;
+        if (posX < 0 || posX >= OO_GRID_COLS || posY < 0 || posY >= OO_GRID_ROWS) continue;
+        cellof[i] = posX * OO_GRID_ROWS + posY;
+        start[cellof[i] + 1]++;
+    }
+    for (int c = 0; c < OO_GRID_COLS * OO_GRID_ROWS; c++) start[c + 1] += start[c];
+    int *fill = (int *)malloc(sizeof(int) * (OO_GRID_COLS * OO_GRID_ROWS + 1));
+    memcpy(fill, start, sizeof(int) * (OO_GRID_COLS * OO_GRID_ROWS + 1));
+    int *list = (int *)malloc(sizeof(int) * (n > 0 ? n : 1));
+    for (int i = 0; i < n; i++)
+        if (cellof[i] >= 0) list[fill[cellof[i]]++] = i;
+
+    int total = 0;
+    for (int q = 0; q < Q; q++) {
+        cand_off[q] = total;
+        const float x = qx[q], y = qy[q], r = qr[q];
+        const int minLevel = qmin[q], maxLevel = qmax[q];
+        const int nMinCellX = imax(0, (int)floorf((x - minX - r) * invW));
+        if (nMinCellX >= OO_GRID_COLS) continue;
+        const int nMaxCellX = imin(OO_GRID_COLS - 1, (int)ceilf((x - minX + r) * invW));
+        if (nMaxCellX < 0) continue;
+        const int nMinCellY = imax(0, (int)floorf((y - minY - r) * invH));
+        if (nMinCellY >= OO_GRID_ROWS) continue;
+        const int nMaxCellY = imin(OO_GRID_ROWS - 1, (int)ceilf((y - minY + r) * invH));
+        if (nMaxCellY < 0) continue;
+        const int bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c = ix * OO_GRID_ROWS + iy;
+                for (int j = start[c]; j < start[c + 1]; j++) {
+                    const oo_keypoint *kp = &kps[list[j]];
+                    if (bCheckLevels) {
+                        if (kp->octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp->octave > maxLevel) continue;
+                    }
+                    const float distx = kp->x - x, disty = kp->y - y;
+                    if (fabsf(distx) < r && fabsf(disty) < r) {
+                        if (cand_idx && total < cap) cand_idx[total] = list[j];
+                        total++;
+                    }
+                }
+            }
+    }
+    cand_off[Q] = total;
+    free(start); free(cellof); free(fill); free(list);
+    return total;
+}

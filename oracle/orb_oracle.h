@@ -153,6 +153,15 @@ int oo_stereo_classic(const oo_extractor *exl, const oo_extractor *exr,
                       float mbf, float mb,
                       int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth);
 
+/* Frame::AssignFeaturesToGrid + PosInGrid (src/Frame.cc:536-551, :724-734) and
+ * Frame::GetFeaturesInArea (:669-722) on a 64 x 48 grid (include/Frame.h:92-93): candidate
+ * lists of Q queries in CSR form, each in the reference's order (cell columns, then cell rows,
+ * then ascending keypoint index).  Returns the total number of candidates (cand_idx may be NULL
+ * to count only); cand_off has Q+1 entries. */
+int oo_features_in_area(const oo_keypoint *kps, int n, float minX, float minY, float invW, float invH,
+                        const float *qx, const float *qy, const float *qr, const int32_t *qmin,
+                        const int32_t *qmax, int Q, int32_t *cand_off, int32_t *cand_idx, int cap);
+
 #ifdef __cplusplus
 }
 #endif

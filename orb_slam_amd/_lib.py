@@ -58,6 +58,11 @@ SIGNATURES = {
     "orbx_stereo_match_sad": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _ip]),
     "orbx_stereo_match_sad_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f,
                                           _vp, _vp, _vp, _vp, _vp]),
+    "orbx_features_in_area": (_i, [_vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _ip]),
+    "orbx_grid_search": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                              _vp, _vp, _vp, _vp, _vp, _vp]),
+    "orbx_grid_search_device": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp]),
 }

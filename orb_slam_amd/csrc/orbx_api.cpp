@@ -71,6 +71,7 @@ struct orbx_ctx {
     DevBuf in, out_kps, out_desc, out_n;
     // scratch for matching
     DevBuf partial, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
+    DevBuf grid_start, grid_list, gq[12];
 
     int last_nframes = 0;
     bool have_pyramid = false, have_features = false;
@@ -315,7 +316,8 @@ void orbx_destroy(orbx_ctx* c)
     DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
-                      &c->m7, &c->m8, &c->m9};
+                      &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
+                      &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11]};
     for (DevBuf* b : bufs) b->release();
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->events_ok)
@@ -847,6 +849,146 @@ int orbx_stereo_match_sad(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* kl, con
     HIPCHECK(c, hipMemcpyAsync(&nm, c->m4.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     *nmatched = nm;
+    return ORBX_OK;
+}
+
+static int grid_prepare(orbx_ctx* c, const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch,
+                        float min_x, float min_y, float inv_w, float inv_h)
+{
+    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
+    const size_t need_s = (size_t)nbatch * (kFrameGridCells + 1) * 4, need_l = (size_t)nbatch * stride * 4;
+    if (need_s > c->grid_start.bytes || need_l > c->grid_list.bytes) {
+        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, c->grid_start.ensure(need_s));
+        HIPCHECK(c, c->grid_list.ensure(need_l));
+    }
+    launch_grid_build(d_kps, d_n, N, stride, nbatch, min_x, min_y, inv_w, inv_h, c->grid_start.as<int>(),
+                      c->grid_list.as<int>(), c->stream);
+    return ORBX_OK;
+}
+
+int orbx_grid_search_device(orbx_ctx* c, const orbx_keypoint* d_kps, const uint32_t* d_desc, const int32_t* d_n, int N,
+                            int stride, int nbatch, float min_x, float min_y, float inv_w, float inv_h, const float* d_qx,
+                            const float* d_qy, const float* d_qr, const int32_t* d_qmin, const int32_t* d_qmax,
+                            const uint32_t* d_qdesc, const int32_t* d_nq, int Q, int q_stride, int32_t* d_best_idx,
+                            int32_t* d_best_dist, int32_t* d_second_dist, int32_t* d_best_lvl, int32_t* d_second_lvl,
+                            int32_t* d_ncand)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (!d_kps || !d_desc || !d_qx || !d_qy || !d_qr || !d_qmin || !d_qmax || !d_qdesc || !d_best_idx || !d_best_dist || !d_second_dist)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (N < 0 || stride < 1 || N > stride || nbatch < 1 || nbatch > 65535 || Q < 0 || q_stride < Q)
+        return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (q_stride == 0) return ORBX_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    int rc = grid_prepare(c, d_kps, d_n, N, stride, nbatch, min_x, min_y, inv_w, inv_h);
+    if (rc != ORBX_OK) return rc;
+    launch_grid_search(d_kps, d_desc, c->grid_start.as<int>(), c->grid_list.as<int>(), stride, nbatch, d_qx, d_qy, d_qr,
+                       d_qmin, d_qmax, d_qdesc, d_nq, Q, q_stride, min_x, min_y, inv_w, inv_h, d_best_idx, d_best_dist,
+                       d_second_dist, d_best_lvl, d_second_lvl, d_ncand, nullptr, nullptr, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+// uploads one frame's keypoints and Q queries into the gq[] scratch buffers
+static int grid_upload(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, const float* qx, const float* qy,
+                       const float* qr, const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, int Q)
+{
+    if (!kps || !qx || !qy || !qr || !qmin || !qmax) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)(N > 0 ? N : 1), q = (size_t)Q;
+    HIPCHECK(c, c->gq[0].ensure(n * sizeof(orbx_keypoint)));
+    HIPCHECK(c, c->gq[1].ensure(n * 32));
+    for (int k = 2; k <= 6; k++) HIPCHECK(c, c->gq[k].ensure(q * 4));
+    HIPCHECK(c, c->gq[7].ensure(q * 32));
+    for (int k = 8; k <= 11; k++) HIPCHECK(c, c->gq[k].ensure((q + 1) * 4 * 2));
+    if (N > 0) HIPCHECK(c, hipMemcpyAsync(c->gq[0].p, kps, (size_t)N * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
+    if (N > 0 && desc) HIPCHECK(c, hipMemcpyAsync(c->gq[1].p, desc, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->gq[2].p, qx, q * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->gq[3].p, qy, q * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->gq[4].p, qr, q * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->gq[5].p, qmin, q * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(c->gq[6].p, qmax, q * 4, hipMemcpyHostToDevice, c->stream));
+    if (qdesc) HIPCHECK(c, hipMemcpyAsync(c->gq[7].p, qdesc, q * 32, hipMemcpyHostToDevice, c->stream));
+    return ORBX_OK;
+}
+
+int orbx_grid_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y,
+                     float inv_w, float inv_h, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                     const int32_t* qmax, const uint32_t* qdesc, int Q, int32_t* best_idx, int32_t* best_dist,
+                     int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl, int32_t* ncand)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (N < 0 || Q < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (Q == 0) return ORBX_OK;
+    if (!qdesc || !best_idx || !best_dist || !second_dist || (N > 0 && !desc)) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (N > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
+    int rc = grid_upload(c, kps, desc, N, qx, qy, qr, qmin, qmax, qdesc, Q);
+    if (rc != ORBX_OK) return rc;
+    const int stride = N > 0 ? N : 1;
+    int32_t* o = c->gq[8].as<int32_t>();     // best_idx | best_dist
+    int32_t* o2 = c->gq[9].as<int32_t>();    // second_dist | best_lvl
+    int32_t* o3 = c->gq[10].as<int32_t>();   // second_lvl | ncand
+    rc = orbx_grid_search_device(c, c->gq[0].as<orbx_keypoint>(), c->gq[1].as<uint32_t>(), nullptr, N, stride, 1, min_x,
+                                 min_y, inv_w, inv_h, c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(),
+                                 c->gq[5].as<int32_t>(), c->gq[6].as<int32_t>(), c->gq[7].as<uint32_t>(), nullptr, Q, Q,
+                                 o, o + Q + 1, o2, o2 + Q + 1, o3, o3 + Q + 1);
+    if (rc != ORBX_OK) return rc;
+    const size_t qb = (size_t)Q * 4;
+    HIPCHECK(c, hipMemcpyAsync(best_idx, o, qb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(best_dist, o + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipMemcpyAsync(second_dist, o2, qb, hipMemcpyDeviceToHost, c->stream));
+    if (best_lvl) HIPCHECK(c, hipMemcpyAsync(best_lvl, o2 + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
+    if (second_lvl) HIPCHECK(c, hipMemcpyAsync(second_lvl, o3, qb, hipMemcpyDeviceToHost, c->stream));
+    if (ncand) HIPCHECK(c, hipMemcpyAsync(ncand, o3 + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
+int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float min_x, float min_y, float inv_w, float inv_h,
+                          const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int Q,
+                          int32_t* cand_off, int32_t* cand_idx, int cap, int* total)
+{
+    if (!c || !total) return ORBX_ERR_INVALID;
+    *total = 0;
+    if (N < 0 || Q < 0 || !cand_off) return fail(c, ORBX_ERR_INVALID, "bad arguments");
+    cand_off[0] = 0;
+    if (Q == 0) return ORBX_OK;
+    if (N > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
+    int rc = grid_upload(c, kps, nullptr, N, qx, qy, qr, qmin, qmax, nullptr, Q);
+    if (rc != ORBX_OK) return rc;
+    const int stride = N > 0 ? N : 1;
+    rc = grid_prepare(c, c->gq[0].as<orbx_keypoint>(), nullptr, N, stride, 1, min_x, min_y, inv_w, inv_h);
+    if (rc != ORBX_OK) return rc;
+    int32_t* d_cnt = c->gq[8].as<int32_t>();
+    int32_t* d_off = c->gq[9].as<int32_t>();
+    // pass 1: count
+    launch_grid_search(c->gq[0].as<orbx_keypoint>(), nullptr, c->grid_start.as<int>(), c->grid_list.as<int>(), stride, 1,
+                       c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(), c->gq[5].as<int32_t>(),
+                       c->gq[6].as<int32_t>(), nullptr, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, d_cnt, nullptr, nullptr, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    std::vector<int32_t> cnt(Q);
+    HIPCHECK(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    long long sum = 0;
+    for (int q = 0; q < Q; q++) { cand_off[q] = (int32_t)sum; sum += cnt[q]; }
+    if (sum > 0x7fffffffLL) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates");
+    cand_off[Q] = (int32_t)sum;
+    *total = (int)sum;
+    if (sum == 0) return ORBX_OK;
+    if (!cand_idx || cap < sum) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
+    // pass 2: fill
+    HIPCHECK(c, c->gq[11].ensure((size_t)sum * 4));
+    HIPCHECK(c, hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    launch_grid_search(c->gq[0].as<orbx_keypoint>(), nullptr, c->grid_start.as<int>(), c->grid_list.as<int>(), stride, 1,
+                       c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(), c->gq[5].as<int32_t>(),
+                       c->gq[6].as<int32_t>(), nullptr, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, d_off, c->gq[11].as<int32_t>(), c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(cand_idx, c->gq[11].p, (size_t)sum * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
     return ORBX_OK;
 }
 

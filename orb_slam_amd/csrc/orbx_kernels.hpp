@@ -78,4 +78,14 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
                            int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
                            int32_t* d_nmatched, hipStream_t s);
 
+constexpr int kFrameGridCells = 64 * 48;   // FRAME_GRID_COLS x FRAME_GRID_ROWS, include/Frame.h:92-93
+void launch_grid_build(const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch, float minX,
+                       float minY, float invW, float invH, int* d_cell_start, int* d_cell_list, hipStream_t s);
+void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, const int* d_cell_start,
+                        const int* d_cell_list, int stride, int nbatch, const float* qx, const float* qy, const float* qr,
+                        const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, const int32_t* d_nq, int Q,
+                        int q_stride, float minX, float minY, float invW, float invH, int32_t* best_idx,
+                        int32_t* best_dist, int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl, int32_t* ncand,
+                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s);
+
 } // namespace orbx

@@ -498,4 +498,174 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
                        mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
 }
 
+// ---------------------------------------------------------------------------
+// Frame grid: AssignFeaturesToGrid / PosInGrid (src/Frame.cc:536-551, :724-734)
+// and GetFeaturesInArea (:669-722), 64 x 48 cells (include/Frame.h:92-93).
+// k_grid_build: one workgroup per frame; counting sort of the keypoints by cell
+// that keeps ascending keypoint index inside a cell (push_back order).
+// k_grid_search: one thread per query walks its cell range in the reference's
+// order (cell columns, then rows, then the cell's list) and either counts /
+// lists the candidates or feeds them straight into the best / second-best keys.
+// ---------------------------------------------------------------------------
+constexpr int kGridCols = 64, kGridRows = 48, kGridCells = kGridCols * kGridRows;
+
+__global__ __launch_bounds__(256) void k_grid_build(const orbx_keypoint* __restrict__ kps, const int32_t* __restrict__ n_arr,
+                                                    int N, int stride, float minX, float minY, float invW, float invH,
+                                                    int* __restrict__ cell_start, int* __restrict__ cell_list)
+{
+    __shared__ int s_cnt[kGridCells];
+    __shared__ short s_cell[kStereoMaxRight];
+    __shared__ int s_wsum[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int n = min(n_arr ? n_arr[b] : N, min(stride, kStereoMaxRight));
+    kps += (size_t)b * stride;
+    cell_start += (size_t)b * (kGridCells + 1);
+    cell_list += (size_t)b * stride;
+    for (int c = tid; c < kGridCells; c += 256) s_cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int posX = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, minX), invW));
+        const int posY = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, minY), invH));
+        int c = -1;
+        if (!(posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows)) {
+            c = posX * kGridRows + posY;
+            atomicAdd(&s_cnt[c], 1);
+        }
+        s_cell[i] = (short)c;
+    }
+    __syncthreads();
+    // exclusive scan of the 3072 counts: 12 per thread
+    int local[12], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) { local[k] = s_cnt[tid * 12 + k]; sum += local[k]; }
+    int incl = sum;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(incl, d, 64); if (lane >= d) incl += t; }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 12; k++) { s_cnt[tid * 12 + k] = base; cell_start[tid * 12 + k] = base; base += local[k]; }
+    if (tid == 255) cell_start[kGridCells] = base;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int c = s_cell[i];
+        if (c < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < i; j++) rank += (s_cell[j] == c);
+        cell_list[s_cnt[c] + rank] = i;
+    }
+}
+
+struct GridQueryArgs {
+    const float *qx, *qy, *qr;
+    const int32_t *qmin, *qmax;
+    const uint32_t* qdesc;          // NULL: count / list only
+    const int32_t* nq;              // per batch, or NULL
+    int Q, q_stride;
+};
+
+template <bool LIST>
+__global__ __launch_bounds__(256) void k_grid_search(const orbx_keypoint* __restrict__ kps, const uint32_t* __restrict__ desc,
+                                                     const int* __restrict__ cell_start, const int* __restrict__ cell_list,
+                                                     int stride, GridQueryArgs a, float minX, float minY, float invW, float invH,
+                                                     int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                     int32_t* __restrict__ second_dist, int32_t* __restrict__ best_lvl,
+                                                     int32_t* __restrict__ second_lvl, int32_t* __restrict__ ncand,
+                                                     const int32_t* __restrict__ cand_off, int32_t* __restrict__ cand_idx)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const int nQ = a.nq ? min(a.nq[b], a.q_stride) : a.Q;
+    if (q >= nQ) return;
+    kps += (size_t)b * stride;
+    cell_start += (size_t)b * (kGridCells + 1);
+    cell_list += (size_t)b * stride;
+    const size_t qo = (size_t)b * a.q_stride + q;
+    const float x = a.qx[qo], y = a.qy[qo], r = a.qr[qo];
+    const int minLevel = a.qmin[qo], maxLevel = a.qmax[qo];
+    const bool has_desc = a.qdesc != nullptr;
+    uint32_t qd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_desc) {
+        const uint4* qp = reinterpret_cast<const uint4*>(a.qdesc + qo * 8);
+        uint4 u = qp[0], v = qp[1];
+        qd[0] = u.x; qd[1] = u.y; qd[2] = u.z; qd[3] = u.w;
+        qd[4] = v.x; qd[5] = v.y; qd[6] = v.z; qd[7] = v.w;
+        desc += (size_t)b * stride * 8;
+    }
+    uint32_t best = kKeyNone, second = kKeyNone;
+    int bi = -1, si = -1;       // keypoint indices behind the two keys
+    int count = 0;
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+    const int nMaxCellX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+    const int nMaxCellY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+    const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    int wr = LIST ? cand_off[qo] : 0;
+    if (!empty)
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c = ix * kGridRows + iy;
+                for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
+                    const int idx = cell_list[j];
+                    const orbx_keypoint kp = kps[idx];
+                    if (checkLevels) {
+                        if (kp.octave < minLevel) continue;
+                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                    }
+                    if (fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r) {
+                        if (LIST) cand_idx[wr++] = idx;
+                        if (has_desc) {
+                            const uint4* tp = reinterpret_cast<const uint4*>(desc + (size_t)idx * 8);
+                            const int d = hamming256(qd, tp[0], tp[1]);
+                            const uint32_t key = ((uint32_t)d << 22) | (uint32_t)min(count, 0x3FFFFF);
+                            if (key < best) { second = best; si = bi; best = key; bi = idx; }
+                            else if (key < second) { second = key; si = idx; }
+                        }
+                        count++;
+                    }
+                }
+            }
+    if (ncand) ncand[qo] = count;
+    if (has_desc) {
+        const bool bok = (best >> 22) < 256u, sok = (second >> 22) < 256u;
+        best_idx[qo] = bok ? bi : -1;
+        best_dist[qo] = (int32_t)(best >> 22);
+        second_dist[qo] = (int32_t)(second >> 22);
+        if (best_lvl) best_lvl[qo] = bok ? kps[bi].octave : -1;
+        if (second_lvl) second_lvl[qo] = sok ? kps[si].octave : -1;
+    }
+}
+
+void launch_grid_build(const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch, float minX,
+                       float minY, float invW, float invH, int* d_cell_start, int* d_cell_list, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_grid_build, dim3(nbatch), dim3(256), 0, s, d_kps, d_n, N, stride, minX, minY, invW, invH,
+                       d_cell_start, d_cell_list);
+}
+
+void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, const int* d_cell_start,
+                        const int* d_cell_list, int stride, int nbatch, const float* qx, const float* qy, const float* qr,
+                        const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, const int32_t* d_nq, int Q,
+                        int q_stride, float minX, float minY, float invW, float invH, int32_t* best_idx,
+                        int32_t* best_dist, int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl, int32_t* ncand,
+                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s)
+{
+    if (q_stride <= 0) return;
+    GridQueryArgs a{qx, qy, qr, qmin, qmax, qdesc, d_nq, Q, q_stride};
+    dim3 grid((q_stride + 255) / 256, nbatch);
+    if (cand_idx)
+        hipLaunchKernelGGL(k_grid_search<true>, grid, dim3(256), 0, s, d_kps, d_desc, d_cell_start, d_cell_list, stride, a,
+                           minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl, second_lvl, ncand, cand_off,
+                           cand_idx);
+    else
+        hipLaunchKernelGGL(k_grid_search<false>, grid, dim3(256), 0, s, d_kps, d_desc, d_cell_start, d_cell_list, stride, a,
+                           minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl, second_lvl, ncand, cand_off,
+                           cand_idx);
+}
+
 } // namespace orbx

@@ -118,3 +118,45 @@ class ORBmatcher:
         check(self._lib, self._ctx, self._lib.orbx_stereo_match_sad_device(
             self._ctx, right_extractor._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr),
             nbatch, stride, mbf, mb, ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))
+
+    # ---- frame grid (Frame::GetFeaturesInArea) ---------------------------------------------
+    def features_in_area(self, kps, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax):
+        """CSR candidate lists of Frame::GetFeaturesInArea (src/Frame.cc:669-722) for Q queries"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        Q = len(qx)
+        off = np.zeros(Q + 1, np.int32)
+        total = C.c_int32()
+        cap = max(len(kps) * 8, 1024)
+        while True:
+            idx = np.zeros(cap, np.int32)
+            rc = self._lib.orbx_features_in_area(self._ctx, kps.ctypes.data, len(kps), min_x, min_y, inv_w, inv_h,
+                                                 qx.ctypes.data, qy.ctypes.data, qr.ctypes.data, qmin.ctypes.data,
+                                                 qmax.ctypes.data, Q, off.ctypes.data, idx.ctypes.data, cap, C.byref(total))
+            if rc == -4 and total.value > cap:
+                cap = total.value
+                continue
+            check(self._lib, self._ctx, rc)
+            return off, idx[:total.value]
+
+    def grid_search(self, kps, desc, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax, qdesc):
+        """GetFeaturesInArea fused with the best / second-best scan (src/ORBmatcher.cc:186-225)"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc, qdesc = _desc(desc), _desc(qdesc)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        Q = len(qx)
+        outs = [np.zeros(max(Q, 1), np.int32) for _ in range(6)]
+        check(self._lib, self._ctx, self._lib.orbx_grid_search(
+            self._ctx, kps.ctypes.data, desc.ctypes.data, len(kps), min_x, min_y, inv_w, inv_h, qx.ctypes.data,
+            qy.ctypes.data, qr.ctypes.data, qmin.ctypes.data, qmax.ctypes.data, qdesc.ctypes.data, Q,
+            *[o.ctypes.data for o in outs]))
+        return tuple(o[:Q] for o in outs)
+
+    def grid_search_device(self, d_kps, d_desc, d_n, N, stride, nbatch, min_x, min_y, inv_w, inv_h,
+                           d_qx, d_qy, d_qr, d_qmin, d_qmax, d_qdesc, d_nq, Q, q_stride, d_bi, d_bd, d_sd, d_bl, d_sl, d_nc):
+        check(self._lib, self._ctx, self._lib.orbx_grid_search_device(
+            self._ctx, ptr(d_kps), ptr(d_desc), ptr(d_n), N, stride, nbatch, min_x, min_y, inv_w, inv_h,
+            ptr(d_qx), ptr(d_qy), ptr(d_qr), ptr(d_qmin), ptr(d_qmax), ptr(d_qdesc), ptr(d_nq), Q, q_stride,
+            ptr(d_bi), ptr(d_bd), ptr(d_sd), ptr(d_bl), ptr(d_sl), ptr(d_nc)))

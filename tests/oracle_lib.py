@@ -71,6 +71,8 @@ class Oracle:
                                          C.c_float, C.c_float, C.c_float, _f32p, _f32p]
         lib.oo_stereo_classic.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int,
                                           C.c_float, C.c_float, _i32p, _i32p, _f32p, _f32p]
+        lib.oo_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                            _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -279,3 +281,16 @@ class Oracle:
                                         kr.ctypes.data, _ptr(dr.view(np.uint32), _u32p), len(kr), mbf, mb,
                                         _ptr(bi, _i32p), _ptr(bd, _i32p), _ptr(ur, _f32p), _ptr(dp, _f32p))
         return bi[:len(kl)], bd[:len(kl)], ur[:len(kl)], dp[:len(kl)], nm
+
+    def features_in_area(self, kps, minX, minY, invW, invH, qx, qy, qr, qmin, qmax):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        qx, qy, qr = (np.ascontiguousarray(a, np.float32) for a in (qx, qy, qr))
+        qmin, qmax = (np.ascontiguousarray(a, np.int32) for a in (qmin, qmax))
+        Q = len(qx)
+        off = np.zeros(Q + 1, np.int32)
+        args = (kps.ctypes.data, len(kps), minX, minY, invW, invH, _ptr(qx, _f32p), _ptr(qy, _f32p), _ptr(qr, _f32p),
+                _ptr(qmin, _i32p), _ptr(qmax, _i32p), Q, _ptr(off, _i32p))
+        total = self.lib.oo_features_in_area(*args, None, 0)
+        idx = np.zeros(max(total, 1), np.int32)
+        self.lib.oo_features_in_area(*args, _ptr(idx, _i32p), total)
+        return off, idx[:total]

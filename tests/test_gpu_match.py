@@ -178,3 +178,44 @@ def test_stereo_classic_sad_refinement(ex, matcher):
         assert np.array_equal(ur, our) and np.array_equal(dp, odp)       # float results bit-identical
         assert (ur >= 0).sum() > 100
     exr.close()
+
+
+def _grid_queries(rng, kps, Q):
+    pick = rng.integers(0, len(kps), Q)
+    qx = (kps["x"][pick] + rng.normal(0, 6, Q)).astype(np.float32)
+    qy = (kps["y"][pick] + rng.normal(0, 6, Q)).astype(np.float32)
+    qx[:8] = [-50, 800, 10, 740, 376, 0, 751.5, 300]          # outside / at the borders
+    qy[:8] = [100, 100, -40, 500, 240, 0, 479.5, 479]
+    qr = rng.uniform(2, 40, Q).astype(np.float32)
+    qmin = rng.integers(-1, 4, Q).astype(np.int32)
+    qmax = np.where(rng.random(Q) < 0.3, -1, qmin + rng.integers(0, 4, Q)).astype(np.int32)
+    return qx, qy, qr, qmin, qmax, pick
+
+
+def test_grid_candidates_and_fused_search(ex, matcher, oracle, euroc_left):
+    """Frame::GetFeaturesInArea candidate lists (CSR, reference order) and the fused grid search."""
+    rng = np.random.default_rng(21)
+    kps, desc = ex(euroc_left)
+    # grid constants of an undistorted 752x480 frame: src/Frame.cc:134-135
+    min_x, min_y = 0.0, 0.0
+    inv_w, inv_h = float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480))
+    Q = 700
+    qx, qy, qr, qmin, qmax, pick = _grid_queries(rng, kps, Q)
+    off_o, idx_o = oracle.features_in_area(kps, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    off_g, idx_g = matcher.features_in_area(kps, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    assert np.array_equal(off_g, off_o) and np.array_equal(idx_g, idx_o)
+    assert off_o[-1] > 3 * Q
+    qdesc = desc[pick].copy()
+    flip = rng.integers(0, 256, Q)
+    qdesc[np.arange(Q), flip // 8] ^= (1 << (flip % 8)).astype(np.uint8)
+    got = matcher.grid_search(kps, desc, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax, qdesc)
+    ref = oracle.match_windowed(qdesc, desc, off_o, idx_o, kps["octave"])
+    for g_, r_, name in zip(got[:5], ref, ["best_idx", "best_dist", "second_dist", "best_lvl", "second_lvl"]):
+        assert np.array_equal(g_, r_), name
+    assert np.array_equal(got[5], np.diff(off_o))
+    # keypoints outside the grid (undistortion can push them out) are not listed
+    k2 = kps.copy()
+    k2["x"][:40] -= 700
+    off_o, idx_o = oracle.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    off_g, idx_g = matcher.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    assert np.array_equal(off_g, off_o) and np.array_equal(idx_g, idx_o)

@@ -388,3 +388,47 @@ def test_stereo_row_band_semantics(oracle):
     assert (bi[0], bd[0]) == (0, 2)
     # left 1 (octave 2): right 2 is in the row band but its octave 4 is two levels away
     assert (bi[1], bd[1]) == (0, 100)
+
+
+def test_features_in_area_against_python(oracle):
+    """Frame::GetFeaturesInArea restated naively in Python (lists per grid cell)."""
+    rng = np.random.default_rng(12)
+    n = 400
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(-20, 780, n).astype(np.float32)
+    kps["y"] = rng.uniform(-20, 500, n).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    minx, miny = np.float32(0), np.float32(0)
+    invw, invh = np.float32(64) / np.float32(752), np.float32(48) / np.float32(480)
+    grid = {}
+    for i in range(n):
+        px = int(np.floor(abs(v := (kps["x"][i] - minx) * invw) + np.float32(0.5)) * (1 if v >= 0 else -1))
+        py = int(np.floor(abs(v := (kps["y"][i] - miny) * invh) + np.float32(0.5)) * (1 if v >= 0 else -1))
+        if 0 <= px < 64 and 0 <= py < 48:
+            grid.setdefault((px, py), []).append(i)
+    Q = 120
+    qx = rng.uniform(-30, 790, Q).astype(np.float32)
+    qy = rng.uniform(-30, 510, Q).astype(np.float32)
+    qr = rng.uniform(3, 60, Q).astype(np.float32)
+    qmin = rng.integers(-1, 4, Q).astype(np.int32)
+    qmax = np.where(rng.random(Q) < 0.4, -1, qmin + 2).astype(np.int32)
+    off, idx = oracle.features_in_area(kps, float(minx), float(miny), float(invw), float(invh), qx, qy, qr, qmin, qmax)
+    for q in range(Q):
+        x, y, r = qx[q], qy[q], qr[q]
+        exp = []
+        x0 = max(0, int(np.floor((x - minx - r) * invw)))
+        x1 = min(63, int(np.ceil((x - minx + r) * invw)))
+        y0 = max(0, int(np.floor((y - miny - r) * invh)))
+        y1 = min(47, int(np.ceil((y - miny + r) * invh)))
+        if not (x0 >= 64 or x1 < 0 or y0 >= 48 or y1 < 0):
+            check = qmin[q] > 0 or qmax[q] >= 0
+            for ix in range(x0, x1 + 1):
+                for iy in range(y0, y1 + 1):
+                    for i in grid.get((ix, iy), []):
+                        o = kps["octave"][i]
+                        if check and (o < qmin[q] or (qmax[q] >= 0 and o > qmax[q])):
+                            continue
+                        if abs(kps["x"][i] - x) < r and abs(kps["y"][i] - y) < r:
+                            exp.append(i)
+        assert list(idx[off[q]:off[q + 1]]) == exp
+    assert off[-1] > Q

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/orbx.h"
 #include "orbx_common.hpp"
@@ -468,17 +469,31 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // lane prefix counts keep the queue, and therefore the output, in row-major
 // order.  Results are identical to k_fast_cells.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
                                                         uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);
-    uint8_t* s_score = smem + fl.score_off;
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(smem + fl.queue_off);
+    // every wavefront of the workgroup handles a cell of its own in its own LDS slice; nothing is
+    // shared between wavefronts, so wave-level fences replace workgroup barriers
+    unsigned char* wmem = smem + (WAVES > 1 ? (threadIdx.x >> 6) * fl.total : 0);
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(wmem);
+    uint8_t* s_score = wmem + fl.score_off;
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(wmem + fl.queue_off);
     const int TP = fl.tile_pitch, SP = fl.score_pitch;
 
-    const int lane = threadIdx.x;
-    const int cell = blockIdx.x, f = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int bx = WAVES > 1 ? (int)(blockIdx.x * WAVES + (threadIdx.x >> 6)) : (int)blockIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); the grid is padded
+    // to a multiple of 64 cells per frame, so blocks x, x+8, x+16, ... share an XCD.  Give them
+    // neighbouring cells: neighbouring tiles share their 3-pixel rings and cache lines.
+    // Groups of 8 consecutive cells go to one XCD, groups round-robin over the XCDs (this also
+    // spreads the more expensive low-level cells evenly).
+    const int seq = (int)(blockIdx.x >> 3) * WAVES + (WAVES > 1 ? (int)(threadIdx.x >> 6) : 0);   // position in this XCD's sequence
+    const int cell = fl.xcd_map ? (((seq >> 3) << 3) + (int)(blockIdx.x & 7)) * 8 + (seq & 7) : bx;
+    const int f = blockIdx.y;
+    if (cell >= g.ncells) return;
     int level = 0;
 #pragma unroll
     for (int l = 1; l < kMaxLevels; l++)
@@ -510,47 +525,60 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         uint32_t* sc32 = reinterpret_cast<uint32_t*>(s_score);
         for (int i = lane; i < ((ch + 2) * SP) >> 2; i += 64) sc32[i] = 0;
     }
-    __syncthreads();
+    WAVE_SYNC();
 
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
     const int npix = cw * ch;
     const uint32_t rcp_cw = ((1u << 18) + cw - 1) / cw;          // i / cw for i < 2^12, cw <= 64
     const int t = g.minTh;
     int nq = 0;
+    // the lane's pixel advances by 64 positions per round: keep its column and tile offset
+    // incrementally instead of dividing every round
+    const int q64 = (int)(__umul24(64u, rcp_cw) >> 18), r64 = 64 - q64 * cw;     // 64 = q64*cw + r64
+    const int adv = q64 * TP + r64, wrap = TP - cw, TP3 = 3 * TP;
+    int px;
+    int addr;
+    {
+        const int py0 = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18);
+        px = lane - __mul24(py0, cw);
+        addr = __mul24(py0 + 3, TP) + px + 3 + ox;
+    }
     for (int i0 = 0; i0 < npix; i0 += 64) {
         const int i = i0 + lane;
         bool pass = false;
         if (i < npix) {
-            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
-            const uint8_t* c = tile8 + (py + 3) * TP + px + 3 + ox;
+            const uint8_t* c = tile8 + addr;
             const int v = c[0], hi = v + t, lo = v - t;
-            const int p0 = c[3 * TP], p4 = c[3], p8 = c[-3 * TP], p12 = c[-3];
+            const int p0 = c[TP3], p4 = c[3], p8 = c[-TP3], p12 = c[-3];
             const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
             const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
             pass = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) ||
                    (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
         }
+        px += r64;
+        addr += adv;
+        if (px >= cw) { px -= cw; addr += wrap; }
         const unsigned long long bal = __ballot(pass);
         if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
         nq += __popcll(bal);
     }
-    __syncthreads();
+    WAVE_SYNC();
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
         if (q < nq) {
             const int i = s_queue[q];
-            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
+            const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
             const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
             s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
         }
     }
-    __syncthreads();
+    WAVE_SYNC();
     bool any = false;
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
         if (q < nq) {
             const int i = s_queue[q];
-            const int py = (int)(((uint32_t)i * rcp_cw) >> 18), px = i - py * cw;
+            const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
             const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
             const int s = sc[0];
             if (s > 0 && s > sc[-1] && s > sc[1] && s > sc[-SP - 1] && s > sc[-SP] && s > sc[-SP + 1] &&
@@ -561,7 +589,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         }
     }
     const bool use_ini = __ballot(any) != 0ull;
-    __syncthreads();
+    WAVE_SYNC();
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
     int base = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
@@ -572,8 +600,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             const int e = s_queue[q];
             if (e & 0x8000) {
                 const int i = e & 0x7fff;
-                py = (int)(((uint32_t)i * rcp_cw) >> 18);
-                px = i - py * cw;
+                py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
+                px = i - __mul24(py, cw);
                 s = s_score[(py + 1) * SP + px + 1];
                 keep = !use_ini || s >= g.iniTh;
             }
@@ -587,6 +615,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     }
     if (lane == 0) *count_out = min(base, L.cell_cap);
 }
+
+#undef WAVE_SYNC
 
 // ---------------------------------------------------------------------------
 // block-wide scans (blockDim.x == 256)
@@ -999,14 +1029,23 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     fl.score_off = (tile_bytes + 15) & ~15;
     fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
     fl.total = fl.queue_off + 2 * wc * hc + 16;
+    fl.total = (fl.total + 15) & ~15;
+    fl.xcd_map = getenv("ORBX_FAST_NO_XCD_MAP") ? 0 : 1;
 }
 
 void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
                             int* cell_count, int nframes, hipStream_t s)
 {
     if (g.ncells == 0) return;
-    dim3 grid(g.ncells, nframes);
-    hipLaunchKernelGGL(k_fast_cells_wave, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
+    const int padded = fl.xcd_map ? ((g.ncells + 63) & ~63) : g.ncells;
+    static const int waves = getenv("ORBX_FAST_WAVES") ? atoi(getenv("ORBX_FAST_WAVES")) : 1;
+    if (waves == 4 && (size_t)fl.total * 4 <= 64 * 1024) {
+        dim3 grid((padded + 3) / 4, nframes);
+        hipLaunchKernelGGL(k_fast_cells_wave<4>, grid, dim3(256), (size_t)fl.total * 4, s, pyr, g, fl, cell_cand, cell_count);
+    } else {
+        dim3 grid(padded, nframes);
+        hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
+    }
 }
 
 size_t quadtree_lds_bytes(int max_nodes) { return quadtree_fixed_lds(max_nodes); }

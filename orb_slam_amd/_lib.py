@@ -49,6 +49,7 @@ SIGNATURES = {
     "orbx_debug_blurred_level": (_i, [_vp, _i, _i, _vp, C.c_size_t]),
     "orbx_stage_times": (_i, [_vp, C.POINTER(C.c_char_p), _fp, _ip, _i]),
     "orbx_reset_stage_times": (_i, [_vp]),
+    "orbx_set_stage_timing": (_i, [_vp, _i]),
     "orbx_hamming": (_i, [_vp, _vp]),
     "orbx_match_bruteforce": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_match_bruteforce_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),

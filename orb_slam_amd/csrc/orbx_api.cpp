@@ -39,10 +39,13 @@ struct DevBuf {
 enum Stage { ST_PYR0 = 0, ST_RESIZE, ST_BLUR, ST_FAST, ST_QUADTREE, ST_DESC, ST_COUNT };
 const char* kStageNames[ST_COUNT] = {"pyr_level0", "pyr_resize", "blur", "fast_cells", "quadtree", "orient_desc"};
 constexpr int kEventSets = 64;
+// stage-timing events only order work on this device: no system-scope cache flush per event
+constexpr unsigned kStageEventFlags = hipEventDisableSystemFence;
 
 struct EventSet {
     hipEvent_t start[ST_COUNT], stop[ST_COUNT];
     bool pending = false;
+    bool chained = false;   // stages ran back to back on one stream: stop[i-1] doubles as start[i]
 };
 
 } // namespace
@@ -81,6 +84,7 @@ struct orbx_ctx {
     // stage timing
     EventSet evs[kEventSets];
     bool events_ok = false;
+    bool stage_timing = true;
     int ev_next = 0;
     double stage_ms[ST_COUNT] = {0};
     int stage_launches[ST_COUNT] = {0};
@@ -115,7 +119,8 @@ void harvest(orbx_ctx* c, EventSet& es)
     (void)hipEventSynchronize(es.stop[ST_BLUR]);
     for (int s = 0; s < ST_COUNT; s++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, es.start[s], es.stop[s]) == hipSuccess) {
+        hipEvent_t from = (es.chained && s > 0) ? es.stop[s - 1] : es.start[s];
+        if (hipEventElapsedTime(&ms, from, es.stop[s]) == hipSuccess) {
             c->stage_ms[s] += ms;
             c->stage_launches[s] += 1;
         }
@@ -189,12 +194,15 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     const FrameGeom& g = c->g;
     hipStream_t s = c->stream;
     EventSet* es = nullptr;
-    if (c->events_ok && !pyramid_only) {
+    if (c->events_ok && c->stage_timing && !pyramid_only) {
         es = &c->evs[c->ev_next];
         c->ev_next = (c->ev_next + 1) % kEventSets;
         harvest(c, *es);
     }
-    auto t0 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->start[i], q); };
+    static const bool want_overlap = getenv("ORBX_OVERLAP") != nullptr;
+    const bool overlap = c->aux_stream && want_overlap && !pyramid_only;
+    if (es) es->chained = !overlap;
+    auto t0 = [&](int i, hipStream_t q) { if (es && (i == 0 || !es->chained)) (void)hipEventRecord(es->start[i], q); };
     auto t1 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->stop[i], q); };
 
     t0(ST_PYR0, s);
@@ -218,8 +226,6 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     // The blur only feeds the descriptors, so it may run on a second stream beside FAST +
     // quadtree (ORBX_OVERLAP=1).  Off by default: the gain is a few percent (both kernels
     // compete for the same CUs) and per-kernel durations stop being separable.
-    static const bool want_overlap = getenv("ORBX_OVERLAP") != nullptr;
-    const bool overlap = c->aux_stream && want_overlap;
     hipStream_t bs = overlap ? c->aux_stream : s;
     if (overlap) {
         HIPCHECK(c, hipEventRecord(c->ev_pyr, s));
@@ -296,7 +302,8 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scaleFactor, int nlevels, i
     c->events_ok = true;
     for (int i = 0; i < kEventSets && c->events_ok; i++)
         for (int j = 0; j < ST_COUNT; j++)
-            if (hipEventCreate(&c->evs[i].start[j]) != hipSuccess || hipEventCreate(&c->evs[i].stop[j]) != hipSuccess) {
+            if (hipEventCreateWithFlags(&c->evs[i].start[j], kStageEventFlags) != hipSuccess ||
+                hipEventCreateWithFlags(&c->evs[i].stop[j], kStageEventFlags) != hipSuccess) {
                 c->events_ok = false;
                 break;
             }
@@ -560,6 +567,13 @@ int orbx_reset_stage_times(orbx_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < kEventSets; i++) harvest(c, c->evs[i]);
     for (int s = 0; s < ST_COUNT; s++) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; }
+    return ORBX_OK;
+}
+
+int orbx_set_stage_timing(orbx_ctx* c, int enable)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    c->stage_timing = enable != 0;
     return ORBX_OK;
 }
 

@@ -58,24 +58,35 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------
 // pyramid
 // ---------------------------------------------------------------------------
-// grid (ceil(pitch/4/256), plane rows, frames); one thread = 4 plane bytes
+// One thread = 16 plane bytes (pitch is a multiple of 64, planes are 64-byte aligned).  Interior
+// runs come in as four dwords when the source is dword-addressable (aligned != 0); border
+// columns and unaligned sources take the byte path.
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ in, int stride, size_t frame_stride,
-                                                    uint8_t* __restrict__ pyr, FrameGeom g)
+                                                    uint8_t* __restrict__ pyr, FrameGeom g, int aligned)
 {
     const LevelGeom& L = g.lv[0];
-    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    const int row = blockIdx.y;
-    if (x4 >= L.pitch) return;
+    const int per_row = L.pitch >> 4;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per_row * L.rows) return;
+    const int row = idx / per_row, x16 = (idx - row * per_row) << 4;
     const int sy = reflect101(row - kPadY, L.h);
-    const uint8_t* src = in + (size_t)blockIdx.z * frame_stride + (size_t)sy * stride;
-    uint32_t v = 0;
+    const uint8_t* src = in + (size_t)blockIdx.y * frame_stride + (size_t)sy * stride;
+    uint32_t v[4];
+    const int sx0 = x16 - kPadX;
+    if (aligned && sx0 >= 0 && sx0 + 16 <= L.w) {
+        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + sx0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int sx = reflect101(x4 + k - kPadX, L.w);
-        v |= (uint32_t)src[sx] << (8 * k);
+        for (int j = 0; j < 4; j++) v[j] = s4[j];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[j] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[j] |= (uint32_t)src[reflect101(sx0 + 4 * j + k, L.w)] << (8 * k);
+        }
     }
-    uint8_t* dst = pyr + (size_t)blockIdx.z * g.pyr_frame_bytes + L.plane_off + (size_t)row * L.pitch + x4;
-    *reinterpret_cast<uint32_t*>(dst) = v;
+    uint8_t* dst = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off + (size_t)row * L.pitch + x16;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 // OpenCV 8-bit bilinear: horizontal pass in 1/2048 units without rounding,
@@ -122,19 +133,11 @@ __device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, pq), __builtin_bit_cast(ushort2_t, a01), 0u, false) >> 4;
 }
 
-__global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr, FrameGeom g, int level,
-                                                      const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
-                                                      int rows_per_band, int ncb)
+// rows [r0, r1) of destination dword column dwc of level L, from level P of the same frame
+__device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, const LevelGeom& P,
+                                            const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
+                                            int dwc, int r0, int r1)
 {
-    const LevelGeom& L = g.lv[level];
-    const LevelGeom& P = g.lv[level - 1];
-    const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int rb = item / ncb, cb = item - rb * ncb;
-    const int dwc = cb * 64 + lane;
-    const int r0 = rb * rows_per_band, r1 = min(r0 + rows_per_band, L.rows);
-    if (dwc * 4 >= L.pitch || r0 >= L.rows) return;
-    uint8_t* frame = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes;
     const XTab4 x = xtab[L.xtab4_off + dwc];
     const uint8_t* src = frame + P.plane_off + x.base;
     uint8_t* dst = frame + L.plane_off + 4 * dwc;
@@ -167,6 +170,20 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
             *reinterpret_cast<uint32_t*>(dst + (size_t)rr[k] * L.pitch) = o;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr, FrameGeom g, int level,
+                                                      const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
+                                                      int rows_per_band, int ncb)
+{
+    const LevelGeom& L = g.lv[level];
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int rb = item / ncb, cb = item - rb * ncb;
+    const int dwc = cb * 64 + lane;
+    const int r0 = rb * rows_per_band, r1 = min(r0 + rows_per_band, L.rows);
+    if (dwc * 4 >= L.pitch || r0 >= L.rows) return;
+    resize_band(pyr + (size_t)blockIdx.y * g.pyr_frame_bytes, L, g.lv[level - 1], xtab, ytab, dwc, r0, r1);
 }
 
 // ---------------------------------------------------------------------------
@@ -1187,8 +1204,9 @@ void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8
                        int nframes, hipStream_t s)
 {
     const LevelGeom& L = g.lv[0];
-    dim3 grid((L.pitch / 4 + 255) / 256, L.rows, nframes);
-    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, in, stride, frame_stride, pyr, g);
+    const int aligned = (((uintptr_t)in | (uintptr_t)frame_stride | (uintptr_t)stride) & 3u) == 0;
+    dim3 grid(((L.pitch >> 4) * L.rows + 255) / 256, nframes);
+    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, in, stride, frame_stride, pyr, g, aligned);
 }
 
 void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,

@@ -192,3 +192,6 @@ class ORBextractor:
 
     def reset_stage_times(self):
         check(self._lib, self._ctx, self._lib.orbx_reset_stage_times(self._ctx))
+
+    def set_stage_timing(self, enable):
+        check(self._lib, self._ctx, self._lib.orbx_set_stage_timing(self._ctx, 1 if enable else 0))

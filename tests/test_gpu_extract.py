@@ -121,6 +121,12 @@ def test_strided_input(gpu, oracle):
     kps_g, desc_g = gpu(view)
     kps_o, desc_o = oracle.extract(np.ascontiguousarray(view))
     _assert_features(kps_g, desc_g, kps_o, desc_o)
+    # source rows that are not dword-addressable (odd column offset, odd stride)
+    big = synthetic_frame(801, 480, 32)
+    view = big[:, 13:13 + 752]
+    kps_g, desc_g = gpu(view)
+    kps_o, desc_o = _compare_frame(gpu, oracle, np.ascontiguousarray(view))
+    _assert_features(kps_g, desc_g, kps_o, desc_o)
 
 
 def test_getters_and_tables(gpu, oracle):

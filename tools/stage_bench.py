@@ -45,6 +45,15 @@ def main():
     st = ex.stage_times()
     print("batch %d x %dx%d: %.3f ms/step, %.0f frames/s, mean kps %.1f" % (B, W, H, ms, B / ms * 1e3, d_n.float().mean().item()))
     print("  " + "  ".join("%s %.3f" % (k, v[0] / max(1, v[1])) for k, v in st.items()))
+    # the same loop without the stage events in the launch sequence
+    ex.set_stage_timing(False)
+    t0.record()
+    for _ in range(steps):
+        ex.extract_batch_device(d_imgs, B, W, H, W, W * H, d_kps, d_desc, cap, d_n)
+    t1.record()
+    torch.cuda.synchronize()
+    ms = t0.elapsed_time(t1) / steps
+    print("without stage events: %.3f ms/step, %.0f frames/s" % (ms, B / ms * 1e3))
 
 
 if __name__ == "__main__":

@@ -1098,17 +1098,23 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // cvRound(float): round half to even
 __device__ __forceinline__ int round_rn(float v) { return __float2int_rn(v); }
 
-// 32 lanes per keypoint, 8 keypoints per workgroup.  grid (ceil(kp_per_frame/8), frames)
+// 32 lanes per keypoint, 8 keypoints per workgroup.  1-D grid of 8 * nbx * ceil(frames/8)
+// workgroups.  Workgroups are dealt round-robin over the 8 XCDs, and the patches of one frame's
+// keypoints overlap heavily, so every frame is given to one XCD (frame f -> XCD f % 8): its
+// planes are then fetched into one L2 once instead of into all eight.
 __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint2* __restrict__ kp_stage,
                                                      const int* __restrict__ level_count,
                                                      orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                     int cap, int* __restrict__ n_out)
+                                                     int cap, int* __restrict__ n_out, int nbx, int nframes)
 {
-    const int f = blockIdx.y;
+    const int seq = blockIdx.x >> 3;                  // position in this XCD's sequence
+    const int fq = seq / nbx, bx = seq - fq * nbx;
+    const int f = fq * 8 + (int)(blockIdx.x & 7);
+    if (f >= nframes) return;
     const int tid = threadIdx.x, lane = tid & 31;
-    const int slot = blockIdx.x * 8 + (tid >> 5);
+    const int slot = bx * 8 + (tid >> 5);
     const int* lc = level_count + f * kMaxLevels;
     int level = -1, k = 0, prefix = 0, total = 0;
 #pragma unroll
@@ -1123,7 +1129,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
             total += c;
         }
     }
-    if (blockIdx.x == 0 && tid == 0) n_out[f] = total;
+    if (bx == 0 && tid == 0) n_out[f] = total;
     if (level < 0 || k >= lc[level]) return;
     const int oi = prefix + k;
     if (oi >= cap) return;
@@ -1324,9 +1330,10 @@ void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* b
                         const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
                         int nframes, hipStream_t s)
 {
-    dim3 grid(g.kp_per_frame > 0 ? (g.kp_per_frame + 7) / 8 : 1, nframes);
+    const int nbx = g.kp_per_frame > 0 ? (g.kp_per_frame + 7) / 8 : 1;
+    dim3 grid((unsigned)(8 * nbx * ((nframes + 7) / 8)));
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, g, pyr, blur, reinterpret_cast<const uint2*>(kp_stage),
-                       level_count, out_kps, out_desc, cap, n_out);
+                       level_count, out_kps, out_desc, cap, n_out, nbx, nframes);
 }
 
 } // namespace orbx

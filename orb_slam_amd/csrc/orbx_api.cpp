@@ -36,8 +36,8 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-enum Stage { ST_PYR0 = 0, ST_RESIZE, ST_BLUR, ST_FAST, ST_QUADTREE, ST_DESC, ST_COUNT };
-const char* kStageNames[ST_COUNT] = {"pyr_level0", "pyr_resize", "blur", "fast_cells", "quadtree", "orient_desc"};
+enum Stage { ST_PYR0 = 0, ST_RESIZE, ST_FAST, ST_BLUR, ST_QUADTREE, ST_DESC, ST_COUNT };   // launch order
+const char* kStageNames[ST_COUNT] = {"pyr_level0", "pyr_resize", "fast_cells", "blur", "quadtree", "orient_desc"};
 constexpr int kEventSets = 64;
 // stage-timing events only order work on this device: no system-scope cache flush per event
 constexpr unsigned kStageEventFlags = hipEventDisableSystemFence;
@@ -199,7 +199,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         c->ev_next = (c->ev_next + 1) % kEventSets;
         harvest(c, *es);
     }
-    static const bool want_overlap = getenv("ORBX_OVERLAP") != nullptr;
+    const char* e_ov = getenv("ORBX_OVERLAP");
+    const bool want_overlap = e_ov && atoi(e_ov) != 0;
     const bool overlap = c->aux_stream && want_overlap && !pyramid_only;
     if (es) es->chained = !overlap;
     auto t0 = [&](int i, hipStream_t q) { if (es && (i == 0 || !es->chained)) (void)hipEventRecord(es->start[i], q); };
@@ -223,9 +224,13 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipGetLastError());
         return ORBX_OK;
     }
-    // The blur only feeds the descriptors, so it may run on a second stream beside FAST +
-    // quadtree (ORBX_OVERLAP=1).  Off by default: the gain is a few percent (both kernels
-    // compete for the same CUs) and per-kernel durations stop being separable.
+    t0(ST_FAST, s);
+    if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    t1(ST_FAST, s);
+    // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
+    // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
+    // puts everything back on one stream; per-stage durations are only separable then).
     hipStream_t bs = overlap ? c->aux_stream : s;
     if (overlap) {
         HIPCHECK(c, hipEventRecord(c->ev_pyr, s));
@@ -236,10 +241,6 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, bs);
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
-    t0(ST_FAST, s);
-    if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
-    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
-    t1(ST_FAST, s);
     t0(ST_QUADTREE, s);
     launch_quadtree(g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), c->cell_off.as<int>(),
                     c->key_xy.as<uint32_t>(), c->key_resp.as<uint8_t>(), c->key_node.as<uint16_t>(), c->kp_stage.p,

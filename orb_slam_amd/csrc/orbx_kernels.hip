@@ -1098,10 +1098,44 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 // cvRound(float): round half to even
 __device__ __forceinline__ int round_rn(float v) { return __float2int_rn(v); }
 
+// sin and cos of a double in [0, 2*pi] (the orientation in radians): quadrant reduction with a
+// two-part pi/2 and the classic degree-13/14 minimax polynomials on [-pi/4, pi/4]; the error is
+// below one unit in the last place of a double, far inside what rounding to float keeps.
+__device__ __forceinline__ void sincos_turn(double x, double* sn, double* cs)
+{
+    const double kd = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-kd, 1.57079632679489655800e+00, x);
+    r = fma(-kd, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double s = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int k = (int)kd;
+    const double s1 = (k & 1) ? c : s, c1 = (k & 1) ? s : c;
+    *sn = (k & 2) ? -s1 : s1;
+    *cs = ((k + 1) & 2) ? -c1 : c1;
+}
+
 // 32 lanes per keypoint, 8 keypoints per workgroup.  1-D grid of 8 * nbx * ceil(frames/8)
 // workgroups.  Workgroups are dealt round-robin over the 8 XCDs, and the patches of one frame's
 // keypoints overlap heavily, so every frame is given to one XCD (frame f -> XCD f % 8): its
 // planes are then fetched into one L2 once instead of into all eight.
+// Descriptor sampling window: the rotated test points stay within 18 pixels of the keypoint
+// (pattern coordinates are within +-13, 13 * sqrt(2) = 18.4), so a 37-row window of 10 aligned
+// dwords per row (37 columns + up to 3 bytes of misalignment) holds every sample.
+constexpr int kDescRadius = 18, kWinRows = 2 * kDescRadius + 1, kWinDw = 10, kWinItems = kWinRows * kWinDw;
+static_assert(kDescRadius <= kPadY && kDescRadius + 3 <= kPadX, "window must stay inside the stored border");
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t* __restrict__ pyr,
                                                      const uint8_t* __restrict__ blur,
                                                      const uint2* __restrict__ kp_stage,
@@ -1109,11 +1143,20 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
                                                      orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
                                                      int cap, int* __restrict__ n_out, int nbx, int nframes)
 {
+    // the 256 test pairs as floats, s_pat[j * 32 + byte] = (x0, y0, x1, y1) of pair 8 * byte + j
+    __shared__ float4 s_pat[256];
+    __shared__ uint32_t s_win[8][kWinItems];
+    const int tid = threadIdx.x, lane = tid & 31;
+    {
+        const int8_t* pp = c_pattern + 4 * tid;
+        s_pat[(tid & 7) * 32 + (tid >> 3)] = make_float4((float)pp[0], (float)pp[1], (float)pp[2], (float)pp[3]);
+    }
+    __syncthreads();
+
     const int seq = blockIdx.x >> 3;                  // position in this XCD's sequence
     const int fq = seq / nbx, bx = seq - fq * nbx;
     const int f = fq * 8 + (int)(blockIdx.x & 7);
     if (f >= nframes) return;
-    const int tid = threadIdx.x, lane = tid & 31;
     const int slot = bx * 8 + (tid >> 5);
     const int* lc = level_count + f * kMaxLevels;
     int level = -1, k = 0, prefix = 0, total = 0;
@@ -1136,11 +1179,27 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     const LevelGeom& L = g.lv[level];
     const uint2 st = kp_stage[(size_t)f * g.kp_per_frame + L.kp_base + k];
     const int x = (int)(st.x & 0xffff) + kDetBorder, y = (int)(st.x >> 16) + kDetBorder;   // :1115-1116
+    const int pitch = L.pitch;
+    const int ctr = (int)L.plane_off + (kPadY + y) * pitch + kPadX + x;   // keypoint, byte offset inside the frame
+
+    // Stage the blurred window of this keypoint in LDS with coalesced dword loads (issued first,
+    // consumed after the orientation): the 16 scattered samples per lane then cost LDS reads
+    // instead of one cache-line lookup each.
+    const uint8_t* bf = blur + (size_t)f * g.pyr_frame_bytes;
+    const int sh = (kPadX + x - kDescRadius) & 3;            // bytes between the aligned window start and column x-18
+    const int win0 = ctr - kDescRadius * pitch - kDescRadius - sh;
+    uint32_t wv[(kWinItems + 31) / 32];
+#pragma unroll
+    for (int t = 0; t < (kWinItems + 31) / 32; t++) {
+        const int i = min(lane + 32 * t, kWinItems - 1);
+        const int r = (i * 6554) >> 16, q = i - r * kWinDw;   // i / 10 for i < 16384
+        wv[t] = *reinterpret_cast<const uint32_t*>(bf + (uint32_t)(win0 + r * pitch + 4 * q));
+    }
 
     // IC_Angle :74-101 on the un-blurred level: lane = patch column u = lane-15, walking the
     // rows |v| <= umax[|u|] of its column (the disc is symmetric in u and v); 31 independent,
     // row-coalesced byte loads per lane, m10 = u * (column sum).
-    const uint8_t* img = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
+    const uint8_t* pf = pyr + (size_t)f * g.pyr_frame_bytes;
     int m10 = 0, m01 = 0;
     {
         const int u = lane - kHalfPatch;
@@ -1151,7 +1210,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
             // unconditional load (rows +-15 of a keypoint always lie inside the plane) so that
             // all 31 loads are in flight together; rows outside the disc contribute zero
             const int av = v < 0 ? -v : v;
-            const int raw = img[v * L.pitch + u];
+            const int raw = pf[(uint32_t)(ctr + v * pitch + u)];
             const int val = av <= d ? raw : 0;
             colsum += val;
             m01 += v * val;
@@ -1165,24 +1224,29 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     }
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
+    uint32_t* win = s_win[tid >> 5];
+#pragma unroll
+    for (int t = 0; t < (kWinItems + 31) / 32; t++)
+        if (lane + 32 * t < kWinItems) win[lane + 32 * t] = wv[t];
+    WAVE_SYNC();
+
     // computeOrbDescriptor :104-150 on the blurred level; lane = descriptor byte
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     const float rad = __fmul_rn(angle, factorPI);
     double sn, cs;
-    sincos((double)rad, &sn, &cs);
+    sincos_turn((double)rad, &sn, &cs);
     const float a = (float)cs, b = (float)sn;
-    const uint8_t* ctr = blur + (size_t)f * g.pyr_frame_bytes + L.plane_off + (size_t)(kPadY + y) * L.pitch + kPadX + x;
-    const int8_t* pat = c_pattern + lane * 32;
+    const uint8_t* win8 = reinterpret_cast<const uint8_t*>(win) + kDescRadius * (4 * kWinDw) + kDescRadius + sh;
     int val = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        float x0 = (float)pat[4 * j], y0 = (float)pat[4 * j + 1], x1 = (float)pat[4 * j + 2], y1 = (float)pat[4 * j + 3];
-        int r0 = round_rn(__fadd_rn(__fmul_rn(x0, b), __fmul_rn(y0, a)));
-        int c0 = round_rn(__fsub_rn(__fmul_rn(x0, a), __fmul_rn(y0, b)));
-        int r1 = round_rn(__fadd_rn(__fmul_rn(x1, b), __fmul_rn(y1, a)));
-        int c1 = round_rn(__fsub_rn(__fmul_rn(x1, a), __fmul_rn(y1, b)));
-        int t0 = ctr[r0 * L.pitch + c0];
-        int t1 = ctr[r1 * L.pitch + c1];
+        const float4 pt = s_pat[j * 32 + lane];
+        const int r0 = round_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
+        const int c0 = round_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
+        const int r1 = round_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
+        const int c1 = round_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
+        const int t0 = win8[r0 * (4 * kWinDw) + c0];
+        const int t1 = win8[r1 * (4 * kWinDw) + c1];
         val |= (t0 < t1) << j;
     }
     out_desc[((size_t)f * cap + oi) * 32 + lane] = (uint8_t)val;
@@ -1202,6 +1266,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
         out_kps[(size_t)f * cap + oi] = kp;
     }
 }
+#undef WAVE_SYNC
 
 // ---------------------------------------------------------------------------
 // launchers

@@ -58,22 +58,36 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------
 // pyramid
 // ---------------------------------------------------------------------------
-// One thread = 16 plane bytes (pitch is a multiple of 64, planes are 64-byte aligned).  Interior
-// runs come in as four dwords when the source is dword-addressable (aligned != 0); border
-// columns and unaligned sources take the byte path.
+// One thread = 16 plane bytes (pitch is a multiple of 64, planes are 64-byte aligned).  Pieces
+// that lie inside the image come in as four dwords when the source is dword-addressable
+// (aligned != 0); pieces touching the left/right border are gathered byte by byte.  The index
+// space lists all interior pieces first and the border pieces after them, so that (all but one)
+// wavefronts run only one of the two paths.
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ in, int stride, size_t frame_stride,
                                                     uint8_t* __restrict__ pyr, FrameGeom g, int aligned)
 {
     const LevelGeom& L = g.lv[0];
     const int per_row = L.pitch >> 4;
+    const int n_int = aligned ? (L.w >> 4) : 0, n_brd = per_row - n_int;
+    const int n_interior = n_int * L.rows;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= per_row * L.rows) return;
-    const int row = idx / per_row, x16 = (idx - row * per_row) << 4;
+    int row, piece;
+    const bool interior = idx < n_interior;
+    if (interior) {
+        row = idx / n_int;
+        piece = (kPadX >> 4) + idx - row * n_int;
+    } else {
+        const int b = idx - n_interior;
+        row = b / n_brd;
+        const int jb = b - row * n_brd;
+        piece = jb < (kPadX >> 4) ? jb : jb + n_int;
+    }
     const int sy = reflect101(row - kPadY, L.h);
     const uint8_t* src = in + (size_t)blockIdx.y * frame_stride + (size_t)sy * stride;
+    const int sx0 = (piece << 4) - kPadX;
     uint32_t v[4];
-    const int sx0 = x16 - kPadX;
-    if (aligned && sx0 >= 0 && sx0 + 16 <= L.w) {
+    if (interior) {
         const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + sx0);
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = s4[j];
@@ -85,7 +99,7 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
             for (int k = 0; k < 4; k++) v[j] |= (uint32_t)src[reflect101(sx0 + 4 * j + k, L.w)] << (8 * k);
         }
     }
-    uint8_t* dst = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off + (size_t)row * L.pitch + x16;
+    uint8_t* dst = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off + (size_t)row * L.pitch + (piece << 4);
     *reinterpret_cast<uint4*>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 

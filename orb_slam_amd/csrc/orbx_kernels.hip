@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rb = item / ncb, cb = item - rb * ncb;
     const int dwc = cb * 64 + lane;
-    const int r0 = rb * rows_per_band, r1 = min(r0 + rows_per_band, L.rows);
+    // the band is the same for the whole wavefront: keep its row numbers in scalar registers so
+    // that the row table comes in through scalar loads instead of one vector load per lane
+    const int r0 = __builtin_amdgcn_readfirstlane(rb * rows_per_band), r1 = min(r0 + rows_per_band, L.rows);
     if (dwc * 4 >= L.pitch || r0 >= L.rows) return;
     resize_band(pyr + (size_t)blockIdx.y * g.pyr_frame_bytes, L, g.lv[level - 1], xtab, ytab, dwc, r0, r1);
 }
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
                                                     FrameGeom g, SlideMap sm)
 {
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform: level, band and column block live in scalar registers
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= sm.base[kMaxLevels]) return;
     int level = 0;
 #pragma unroll

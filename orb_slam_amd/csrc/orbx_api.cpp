@@ -151,7 +151,9 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     HIPCHECK(c, hipStreamSynchronize(c->stream));   // the tables are stack-owned
     c->g = g;
     make_blur_tilemap(c->g, c->tm);
-    make_slide_map(c->g, 64, c->blur_map);
+    // short bands: the kernel is bound by the latency of its dependent row groups, and many short
+    // wavefronts hide it better than few long ones (measured optimum 12 rows, 6 of warm-up included)
+    make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 12, c->blur_map);
     make_fast_lds(c->g, c->fast_lds);
     c->gw = w;
     c->gh = h;

@@ -308,43 +308,65 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     for (int l = 1; l < kMaxLevels; l++)
         if (l < g.nlevels && item >= sm.base[l]) level = l;
     const LevelGeom& L = g.lv[level];
-    const int local = item - sm.base[level];
-    const int rb = local / sm.ncb[level], cb = local - rb * sm.ncb[level];
-    const int dw = cb * 64 + lane;                       // dword column inside the level image
-    if (dw * 4 >= L.w) return;
-    const int y0 = rb * sm.rows[level], y1 = min(y0 + sm.rows[level], L.h);
+    // the level's (band, dword column) pairs are dealt to lanes in one flat sequence, so only the
+    // last wavefront of a level has idle lanes
+    const int flat = (item - sm.base[level]) * 64 + lane;
+    const int ndw = sm.ndw[level];
+    if (flat >= ndw * sm.nrb[level]) return;
+    const int rb = flat / ndw, dw = flat - rb * ndw;     // band, dword column inside the level image
+    const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
     const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
     const uint8_t* src = pyr + fbase + (size_t)(kPadY + y0 - 3) * L.pitch + kPadX + 4 * dw - 4;
     uint8_t* dst = blur + fbase + (size_t)(kPadY + y0) * L.pitch + kPadX + 4 * dw;
     const int pitch = L.pitch;
 
-    // Branch-free schedule: 6 warm-up rows, then groups of 7 rows whose loads are all issued
-    // before the arithmetic.  A band's last group may run past the band (at most 6 rows): those
+    // Branch-free schedule: 6 warm-up rows, then groups of 6 rows whose loads are all issued
+    // before the arithmetic.  A band's last group may run past the band (at most 5 rows): those
     // rows are read from the stored border and written with the same values the next band
     // writes (or into the unused border of the blurred plane).
-    uint32_t h[7][4];
+    // Column pass: the horizontal sums of rows t-1 and t are kept as one packed pair
+    // P[t % 6] = h(t-1) | h(t) << 16, so that output row n-6 (taps = rows n-6 .. n) is three
+    // 2-term dot products over the pairs of times n-5, n-3, n-1 plus the tap of row n.
+    const ushort2_t W01 = {18, 34}, W23 = {49, 55}, W45 = {49, 34};
+    uint32_t P[6][4], hprev[4];
 #pragma unroll
-    for (int p = 0; p < 6; p++) blur_hsum4(src + (size_t)p * pitch, h[p]);
+    for (int p = 0; p < 6; p++) {
+        uint32_t hc[4];
+        blur_hsum4(src + (size_t)p * pitch, hc);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (p > 0) P[p][j] = hprev[j] | (hc[j] << 16);
+            hprev[j] = hc[j];
+        }
+    }
     const int nrows = y1 - y0;
-    for (int r0 = 0; r0 < nrows; r0 += 7) {
+    for (int r0 = 0; r0 < nrows; r0 += 6) {
         const uint8_t* sp = src + (size_t)(r0 + 6) * pitch;
         uint8_t* dp = dst + (size_t)r0 * pitch;
-        uint32_t raw[7][3];
+        uint32_t raw[6][3];
 #pragma unroll
-        for (int p = 0; p < 7; p++) {
+        for (int p = 0; p < 6; p++) {
             const uint32_t* q = reinterpret_cast<const uint32_t*>(sp + (size_t)p * pitch);
             raw[p][0] = q[0]; raw[p][1] = q[1]; raw[p][2] = q[2];
         }
 #pragma unroll
-        for (int p = 0; p < 7; p++) {
-            // row r0+p+6 enters slot (p+6)%7; output row r0+p uses slots (p .. p+6)%7 as taps 0..6
-            blur_hsum4w(raw[p][0], raw[p][1], raw[p][2], h[(p + 6) % 7]);
-            uint32_t o = 0;
+        for (int p = 0; p < 6; p++) {
+            // row n = r0+6+p enters; r0 is a multiple of 6, so time n lives in slot p
+            uint32_t hc[4], acc[4];
+            blur_hsum4w(raw[p][0], raw[p][1], raw[p][2], hc);
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                o |= blur_vsum(h[p % 7][j], h[(p + 1) % 7][j], h[(p + 2) % 7][j], h[(p + 3) % 7][j],
-                               h[(p + 4) % 7][j], h[(p + 5) % 7][j], h[(p + 6) % 7][j]) << (8 * j);
-            *reinterpret_cast<uint32_t*>(dp + (size_t)p * pitch) = o;
+            for (int j = 0; j < 4; j++) {
+                uint32_t s = 18u * hc[j] + 32768u;
+                s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 5) % 6][j]), W45, s, false);
+                s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 3) % 6][j]), W23, s, false);
+                s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 1) % 6][j]), W01, s, false);
+                acc[j] = min(s, 0x00ffffffu);            // byte 2 = min(255, s >> 16)
+                P[p][j] = hprev[j] | (hc[j] << 16);
+                hprev[j] = hc[j];
+            }
+            const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
+            const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+            *reinterpret_cast<uint32_t*>(dp + (size_t)p * pitch) = lo | (hi << 16);
         }
     }
 }
@@ -1341,14 +1363,15 @@ void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
     int base = 0;
     for (int l = 0; l < kMaxLevels; l++) {
         sm.base[l] = base;
-        sm.ncb[l] = 1;
+        sm.ndw[l] = 1;
+        sm.nrb[l] = 0;
         sm.rows[l] = 1;
-        if (l < g.nlevels) {
-            const int ndw = (g.lv[l].w + 3) / 4;
+        if (l < g.nlevels && g.lv[l].w > 0 && g.lv[l].h > 0) {
             const int nrb = (g.lv[l].h + target_rows - 1) / target_rows;
-            sm.ncb[l] = (ndw + 63) / 64;
-            sm.rows[l] = (g.lv[l].h + nrb - 1) / nrb;
-            base += sm.ncb[l] * nrb;
+            sm.ndw[l] = (g.lv[l].w + 3) / 4;
+            sm.nrb[l] = nrb;
+            sm.rows[l] = (g.lv[l].h + nrb - 1) / nrb;      // <= h
+            base += (sm.ndw[l] * nrb + 63) / 64;
         }
     }
     sm.base[kMaxLevels] = base;

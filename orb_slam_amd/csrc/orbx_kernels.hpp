@@ -14,8 +14,9 @@ struct TileMap {
 // work items of the sliding-window kernels: (level, 64-dword column block, row band)
 struct SlideMap {
     int base[kMaxLevels + 1];   // first item of each level; [kMaxLevels] = total
-    int ncb[kMaxLevels];        // column blocks per level
-    int rows[kMaxLevels];       // rows per band
+    int ndw[kMaxLevels];        // dword columns of the level image
+    int nrb[kMaxLevels];        // row bands per level
+    int rows[kMaxLevels];       // rows per band (every band has this many; the last one is shifted up to fit)
 };
 
 // LDS layout of the per-cell FAST kernel, sized for the largest cell of the geometry

@@ -755,7 +755,7 @@ __device__ __forceinline__ int ceil_half(int d)
     return (int)ceilf(__fdiv_rn((float)d, 2.0f));
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
+__device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
                                                   uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
@@ -1072,6 +1072,32 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
     }
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
 }
+
+#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds
+// Two builds of the same body.  k_quadtree keeps every key of a thread in registers (about 210
+// VGPRs, 2 wavefronts per SIMD): lowest latency, used for small batches.  k_quadtree_dense is
+// held to 128 VGPRs (4 wavefronts per SIMD, a few spills): more workgroups in flight, better
+// throughput once a batch has more workgroups than the device holds at once.
+__global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
+                                                  const int* __restrict__ cell_count, int* __restrict__ cell_off,
+                                                  uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
+                                                  uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
+                                                  int* __restrict__ level_count, int* __restrict__ level_ncand,
+                                                  int off_in_lds)
+{
+    quadtree_body(QUADTREE_ARGS);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_quadtree_dense(FrameGeom g, const uint32_t* __restrict__ cell_cand,
+                      const int* __restrict__ cell_count, int* __restrict__ cell_off,
+                      uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
+                      uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
+                      int* __restrict__ level_count, int* __restrict__ level_ncand, int off_in_lds)
+{
+    quadtree_body(QUADTREE_ARGS);
+}
+#undef QUADTREE_ARGS
 
 void make_fast_lds(const FrameGeom& g, FastLds& fl)
 {
@@ -1415,8 +1441,13 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    // 2 workgroups per CU fit with the register-resident build: beyond that the dense build wins
+    if (nframes * g.nlevels > 2 * 256)
+        hipLaunchKernelGGL(k_quadtree_dense, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy,
+                           key_resp, key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    else
+        hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
 }
 
 int quadtree_prepare(int max_nodes)
@@ -1426,6 +1457,9 @@ int quadtree_prepare(int max_nodes)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_dense),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     return 0;

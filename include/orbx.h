@@ -234,6 +234,27 @@ int orbx_grid_search_device(orbx_ctx *ctx, const orbx_keypoint *d_kps, const uin
                             int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist,
                             int32_t *d_best_lvl, int32_t *d_second_lvl, int32_t *d_ncand);
 
+/* --- keypoint undistortion --------------------------------------------------- */
+/* Frame::UndistortKeyPoints / UndistortKeyPointsStereo, src/Frame.cc:745-852: the keypoint
+ * coordinates go through cv::undistortPoints(pts, K, dist, R, P) (fisheye = 0) or
+ * cv::fisheye::undistortPoints (fisheye != 0, the reference's USE_FISHEYE_DISTORTION build);
+ * every other keypoint field is copied.  K: 3x3 row-major; dist: ndist coefficients
+ * (0, 4, 5, 8 or 12 in OpenCV's order k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4; fisheye: 4);
+ * R: 3x3 or NULL (identity); P: 3 x p_cols with p_cols 3 or 4, or NULL (identity) -- the mono
+ * path passes P = K (:839), the stereo path the rectified projection (:771).  The reference's
+ * "first coefficient == 0: plain copy" shortcut (:747, :820) is the caller's.
+ * Host buffers, one frame; kps_out may equal kps_in. */
+int orbx_undistort_keypoints(orbx_ctx *ctx, const orbx_keypoint *kps_in, int n,
+                             const double *K, const double *dist, int ndist,
+                             const double *R, const double *P, int p_cols, int fisheye,
+                             orbx_keypoint *kps_out);
+/* Device-resident, asynchronous, batched: frame b holds d_n[b] keypoints (n if d_n == NULL) at
+ * d_kps_in + b*cap -- the layout orbx_extract_batch_device writes.  d_kps_out may equal d_kps_in. */
+int orbx_undistort_keypoints_device(orbx_ctx *ctx, const orbx_keypoint *d_kps_in, const int32_t *d_n, int n,
+                                    int cap, int nframes, const double *K, const double *dist, int ndist,
+                                    const double *R, const double *P, int p_cols, int fisheye,
+                                    orbx_keypoint *d_kps_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,6 +113,20 @@ private:
     std::vector<int32_t> mnFeaturesPerLevel;
 };
 
+// Frame::UndistortKeyPoints (src/Frame.cc:818-852) and each half of UndistortKeyPointsStereo
+// (:745-816) on the extractor's device: K 3x3 row-major, dist = the mDistCoef entries, R / P null
+// or the rectification (P 3 x p_cols).  A first coefficient of 0 copies, as the reference does.
+inline void UndistortKeyPoints(ORBextractor& ex, const std::vector<orbx_keypoint>& keys, const double* K,
+                               const std::vector<double>& dist, const double* R, const double* P, int p_cols,
+                               bool fisheye, std::vector<orbx_keypoint>& keysUn)
+{
+    keysUn = keys;
+    if (dist.empty() || dist[0] == 0.0 || keys.empty()) return;
+    int rc = orbx_undistort_keypoints(ex.context(), keys.data(), (int)keys.size(), K, dist.data(), (int)dist.size(), R, P,
+                                      p_cols, fisheye ? 1 : 0, keysUn.data());
+    if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ex.context()));
+}
+
 // ORBmatcher::DescriptorDistance (include/ORBmatcher.h:48) on raw 32-byte rows
 inline int DescriptorDistance(const uint8_t* a, const uint8_t* b)
 {

@@ -1422,3 +1422,95 @@ int oo_features_in_area(const oo_keypoint *kps, int n, float minX, float minY, f
     free(start); free(cellof); free(fill); free(list);
     return total;
 }
+
+/* ------------------------------------------------------------------------- *
+ * Keypoint undistortion: Frame::UndistortKeyPoints / UndistortKeyPointsStereo,
+ * src/Frame.cc:745-852.  The reference calls cv::undistortPoints (or, with
+ * USE_FISHEYE_DISTORTION, cv::fisheye::undistortPoints) on the keypoint
+ * coordinates and copies every other keypoint field.
+ *
+ * OpenCV 3.4.1 semantics (restated, parity unpinned like the rest of this file):
+ *  - all arithmetic in double, inputs and outputs are float;
+ *  - RR = P(:, 0:3) * R (identity where a matrix is absent);
+ *  - cv::undistortPoints: x = (u - cx) / fx via ifx = 1/fx; 5 fixed-point iterations
+ *    (default TermCriteria(COUNT, 5)) of
+ *      icdist = (1 + ((k7 r2 + k6) r2 + k5) r2) / (1 + ((k4 r2 + k1) r2 + k0) r2)
+ *      dX = 2 k2 x y + k3 (r2 + 2 x x) + k8 r2 + k9 r2 r2
+ *      dY = k2 (r2 + 2 y y) + 2 k3 x y + k10 r2 + k11 r2 r2
+ *      x = (x0 - dX) icdist, y = (y0 - dY) icdist
+ *    with k = (k1, k2, p1, p2, k3, k4, k5, k6, s1, s2, s3, s4); the tilt model
+ *    (coefficients 13, 14) is not supported;
+ *  - cv::fisheye::undistortPoints: pw = (p - c) / f, theta_d = |pw| clamped to pi/2,
+ *    10 iterations theta = theta_d / (1 + k0 t^2 + k1 t^4 + k2 t^6 + k3 t^8),
+ *    scale = tan(theta) / theta_d (1 when theta_d <= 1e-8);
+ *  - projection x' = (RR0 . (x, y, 1)) / (RR2 . (x, y, 1)).
+ * ------------------------------------------------------------------------- */
+void oo_undistort_rr(const double *R, const double *P, int p_cols, double RR[9])
+{
+    double r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (R) memcpy(r, R, sizeof(r));
+    if (!P) { memcpy(RR, r, sizeof(r)); return; }
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += P[i * p_cols + k] * r[k * 3 + j];
+            RR[i * 3 + j] = s;
+        }
+}
+
+void oo_undistort_points(const float *xy_in, int n, const double K[9], const double *dist, int ndist,
+                         const double *R, const double *P, int p_cols, int fisheye, float *xy_out)
+{
+    double k[12] = {0}, RR[9];
+    for (int i = 0; i < ndist && i < 12; i++) k[i] = dist[i];
+    oo_undistort_rr(R, P, p_cols, RR);
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    for (int i = 0; i < n; i++) {
+        double x, y;
+        if (!fisheye) {
+            x = ((double)xy_in[2 * i] - cx) * ifx;
+            y = ((double)xy_in[2 * i + 1] - cy) * ify;
+            if (ndist > 0) {
+                const double x0 = x, y0 = y;
+                for (int j = 0; j < 5; j++) {
+                    const double r2 = x * x + y * y;
+                    const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+                    const double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+                    const double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+                    x = (x0 - deltaX) * icdist;
+                    y = (y0 - deltaY) * icdist;
+                }
+            }
+        } else {
+            const double pwx = ((double)xy_in[2 * i] - cx) / fx, pwy = ((double)xy_in[2 * i + 1] - cy) / fy;
+            double scale = 1.0;
+            double theta_d = sqrt(pwx * pwx + pwy * pwy);
+            const double half_pi = 3.1415926535897932384626433832795 / 2.;
+            theta_d = fmin(fmax(-half_pi, theta_d), half_pi);
+            if (theta_d > 1e-8) {
+                double theta = theta_d;
+                for (int j = 0; j < 10; j++) {
+                    const double t2 = theta * theta, t4 = t2 * t2, t6 = t4 * t2, t8 = t6 * t2;
+                    theta = theta_d / (1 + k[0] * t2 + k[1] * t4 + k[2] * t6 + k[3] * t8);
+                }
+                scale = tan(theta) / theta_d;
+            }
+            x = pwx * scale;
+            y = pwy * scale;
+        }
+        if (!fisheye) {
+            const double xx = RR[0] * x + RR[1] * y + RR[2];
+            const double yy = RR[3] * x + RR[4] * y + RR[5];
+            const double ww = 1. / (RR[6] * x + RR[7] * y + RR[8]);
+            xy_out[2 * i] = (float)(xx * ww);
+            xy_out[2 * i + 1] = (float)(yy * ww);
+        } else {
+            const double px = RR[0] * x + RR[1] * y + RR[2];
+            const double py = RR[3] * x + RR[4] * y + RR[5];
+            const double pz = RR[6] * x + RR[7] * y + RR[8];
+            xy_out[2 * i] = (float)(px / pz);
+            xy_out[2 * i + 1] = (float)(py / pz);
+        }
+    }
+}

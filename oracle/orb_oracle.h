@@ -162,6 +162,15 @@ int oo_features_in_area(const oo_keypoint *kps, int n, float minX, float minY, f
                         const float *qx, const float *qy, const float *qr, const int32_t *qmin,
                         const int32_t *qmax, int Q, int32_t *cand_off, int32_t *cand_idx, int cap);
 
+/* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
+ * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
+ * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;
+ * R: 3x3 or NULL; P: 3 x p_cols (p_cols = 3 or 4) or NULL.  The caller applies the reference's
+ * "first coefficient is zero: copy" shortcut. */
+void oo_undistort_points(const float *xy_in, int n, const double K[9], const double *dist, int ndist,
+                         const double *R, const double *P, int p_cols, int fisheye, float *xy_out);
+void oo_undistort_rr(const double *R, const double *P, int p_cols, double RR[9]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,8 @@ SIGNATURES = {
                                      _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp]),
+    "orbx_undistort_keypoints": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "orbx_undistort_keypoints_device": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
 }
 
 _lib = None

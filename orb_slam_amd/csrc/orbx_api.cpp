@@ -1009,4 +1009,73 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
     return ORBX_OK;
 }
 
+
+// K, dist, R, P -> the model the kernel evaluates; RR = P(:, 0:3) * R as cv::undistortPoints forms it
+static int undistort_model(orbx_ctx* c, const double* K, const double* dist, int ndist, const double* R, const double* P,
+                           int p_cols, int fisheye, UndistortModel& m)
+{
+    if (!K) return fail(c, ORBX_ERR_INVALID, "camera matrix is required");
+    if (ndist < 0 || (ndist > 0 && !dist)) return fail(c, ORBX_ERR_INVALID, "bad distortion coefficients");
+    if (fisheye ? (ndist != 4) : !(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12))
+        return fail(c, ORBX_ERR_UNSUPPORTED, "distortion vector must have 4, 5, 8 or 12 entries (fisheye: 4); the tilt model is not supported");
+    if (P && p_cols != 3 && p_cols != 4) return fail(c, ORBX_ERR_INVALID, "P must be 3x3 or 3x4");
+    m.fx = K[0]; m.fy = K[4]; m.cx = K[2]; m.cy = K[5];
+    if (m.fx == 0 || m.fy == 0) return fail(c, ORBX_ERR_INVALID, "zero focal length");
+    m.ifx = 1. / m.fx;
+    m.ify = 1. / m.fy;
+    for (int i = 0; i < 12; i++) m.k[i] = i < ndist ? dist[i] : 0.0;
+    double r[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (R) std::memcpy(r, R, sizeof(r));
+    if (!P) std::memcpy(m.RR, r, sizeof(r));
+    else
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += P[i * p_cols + k] * r[k * 3 + j];
+                m.RR[i * 3 + j] = s;
+            }
+    m.ndist = ndist;
+    m.fisheye = fisheye != 0;
+    return ORBX_OK;
+}
+
+int orbx_undistort_keypoints_device(orbx_ctx* c, const orbx_keypoint* d_in, const int32_t* d_n, int n, int cap, int nframes,
+                                    const double* K, const double* dist, int ndist, const double* R, const double* P,
+                                    int p_cols, int fisheye, orbx_keypoint* d_out)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (nframes < 1 || nframes > 65535 || cap < 0 || n < 0 || n > cap) return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (cap == 0) return ORBX_OK;
+    if (!d_in || !d_out) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    UndistortModel m;
+    int rc = undistort_model(c, K, dist, ndist, R, P, p_cols, fisheye, m);
+    if (rc != ORBX_OK) return rc;
+    HIPCHECK(c, hipSetDevice(c->device));
+    launch_undistort(d_in, d_n, n, cap, nframes, m, d_out, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_undistort_keypoints(orbx_ctx* c, const orbx_keypoint* kps_in, int n, const double* K, const double* dist, int ndist,
+                             const double* R, const double* P, int p_cols, int fisheye, orbx_keypoint* kps_out)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (n < 0) return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    UndistortModel m;
+    int rc = undistort_model(c, K, dist, ndist, R, P, p_cols, fisheye, m);   // argument errors even for n == 0
+    if (rc != ORBX_OK) return rc;
+    if (n == 0) return ORBX_OK;
+    if (!kps_in || !kps_out) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    HIPCHECK(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)n * sizeof(orbx_keypoint);
+    HIPCHECK(c, c->gq[0].ensure(bytes));
+    orbx_keypoint* d = c->gq[0].as<orbx_keypoint>();
+    HIPCHECK(c, hipMemcpyAsync(d, kps_in, bytes, hipMemcpyHostToDevice, c->stream));
+    launch_undistort(d, nullptr, n, n, 1, m, d, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipMemcpyAsync(kps_out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    return ORBX_OK;
+}
+
 } // extern "C"

@@ -81,6 +81,16 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
                            int32_t* d_nmatched, hipStream_t s);
 
 constexpr int kFrameGridCells = 64 * 48;   // FRAME_GRID_COLS x FRAME_GRID_ROWS, include/Frame.h:92-93
+// camera model of Frame::UndistortKeyPoints: K, distortion coefficients, RR = P(:, 0:3) * R
+struct UndistortModel {
+    double fx, fy, cx, cy, ifx, ify;
+    double k[12];
+    double RR[9];
+    int ndist, fisheye;
+};
+void launch_undistort(const orbx_keypoint* d_in, const int32_t* d_n, int n_fixed, int cap, int nframes,
+                      const UndistortModel& m, orbx_keypoint* d_out, hipStream_t s);
+
 void launch_grid_build(const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch, float minX,
                        float minY, float invW, float invH, int* d_cell_start, int* d_cell_list, hipStream_t s);
 void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, const int* d_cell_start,

@@ -73,6 +73,8 @@ class Oracle:
                                           C.c_float, C.c_float, _i32p, _i32p, _f32p, _f32p]
         lib.oo_features_in_area.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
                                             _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
+        lib.oo_undistort_points.argtypes = [_f32p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                            C.c_int, C.c_int, _f32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -294,3 +296,15 @@ class Oracle:
         idx = np.zeros(max(total, 1), np.int32)
         self.lib.oo_features_in_area(*args, _ptr(idx, _i32p), total)
         return off, idx[:total]
+
+    def undistort_points(self, xy, K, dist=None, R=None, P=None, fisheye=False):
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        K = np.ascontiguousarray(K, np.float64)
+        d = np.zeros(0, np.float64) if dist is None else np.ascontiguousarray(dist, np.float64).reshape(-1)
+        R = None if R is None else np.ascontiguousarray(R, np.float64)
+        P = None if P is None else np.ascontiguousarray(P, np.float64)
+        out = np.zeros_like(xy)
+        self.lib.oo_undistort_points(_ptr(xy, _f32p), len(xy), K.ctypes.data, d.ctypes.data if len(d) else None, len(d),
+                                     None if R is None else R.ctypes.data, None if P is None else P.ctypes.data,
+                                     0 if P is None else P.shape[1], 1 if fisheye else 0, _ptr(out, _f32p))
+        return out

@@ -432,3 +432,70 @@ def test_features_in_area_against_python(oracle):
                             exp.append(i)
         assert list(idx[off[q]:off[q + 1]]) == exp
     assert off[-1] > Q
+
+
+# ---------------------------------------------------------------------------
+# keypoint undistortion (Frame::UndistortKeyPoints, src/Frame.cc:745-852)
+# ---------------------------------------------------------------------------
+EUROC_K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], np.float64)
+EUROC_D = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05], np.float64)
+
+
+def _distort_plumb_bob(xn, yn, k):
+    """forward model cv::undistortPoints inverts (k1 k2 p1 p2 [k3])"""
+    k = np.concatenate([k, np.zeros(5 - len(k))])
+    r2 = xn * xn + yn * yn
+    rad = 1 + k[0] * r2 + k[1] * r2 * r2 + k[4] * r2 ** 3
+    xd = xn * rad + 2 * k[2] * xn * yn + k[3] * (r2 + 2 * xn * xn)
+    yd = yn * rad + k[2] * (r2 + 2 * yn * yn) + 2 * k[3] * xn * yn
+    return xd, yd
+
+
+def test_undistort_identity_and_projection(oracle):
+    rng = np.random.default_rng(3)
+    xy = (rng.random((200, 2)) * [752, 480]).astype(np.float32)
+    # no distortion, P = K: the map is the identity up to double rounding
+    out = oracle.undistort_points(xy, EUROC_K, None, None, EUROC_K)
+    assert np.abs(out - xy).max() < 1e-3
+    # no P, no R: normalised coordinates
+    out = oracle.undistort_points(xy, EUROC_K)
+    ref = np.stack([(xy[:, 0].astype(np.float64) - 367.215) / 458.654, (xy[:, 1].astype(np.float64) - 248.375) / 457.296], 1)
+    assert np.abs(out - ref).max() < 1e-6
+    # 3x4 P uses its first three columns
+    P34 = np.hstack([EUROC_K, [[-47.9], [0.0], [0.0]]])
+    assert np.array_equal(oracle.undistort_points(xy, EUROC_K, EUROC_D, None, P34),
+                          oracle.undistort_points(xy, EUROC_K, EUROC_D, None, EUROC_K))
+
+
+def test_undistort_inverts_forward_model(oracle):
+    rng = np.random.default_rng(4)
+    xn = (rng.random(500) - 0.5) * 1.2
+    yn = (rng.random(500) - 0.5) * 0.8
+    for k in (EUROC_D, np.array([-0.28, 0.07, 1e-4, -2e-4, 0.01])):
+        xd, yd = _distort_plumb_bob(xn, yn, k)
+        uv = np.stack([xd * 458.654 + 367.215, yd * 457.296 + 248.375], 1).astype(np.float32)
+        out = oracle.undistort_points(uv, EUROC_K, k)
+        # 5 fixed-point iterations: converged to ~1e-4 in normalised units at these radii
+        assert np.abs(out[:, 0] - xn).max() < 2e-3 and np.abs(out[:, 1] - yn).max() < 2e-3
+        # a rotation about the optical axis by 90 degrees maps (x, y) to (-y, x)
+        Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1]], np.float64)
+        outr = oracle.undistort_points(uv, EUROC_K, k, Rz)
+        assert np.allclose(outr[:, 0], -out[:, 1], atol=1e-6) and np.allclose(outr[:, 1], out[:, 0], atol=1e-6)
+
+
+def test_undistort_fisheye_inverts_forward_model(oracle):
+    rng = np.random.default_rng(5)
+    k = np.array([-0.01, 0.02, -0.005, 0.001])
+    xn = (rng.random(500) - 0.5) * 1.6
+    yn = (rng.random(500) - 0.5) * 1.2
+    r = np.hypot(xn, yn)
+    th = np.arctan(r)
+    thd = th * (1 + k[0] * th ** 2 + k[1] * th ** 4 + k[2] * th ** 6 + k[3] * th ** 8)
+    s = np.where(r > 1e-8, thd / np.maximum(r, 1e-30), 1.0)
+    uv = np.stack([xn * s * 380.0 + 376.0, yn * s * 380.0 + 240.0], 1).astype(np.float32)
+    K = np.array([[380.0, 0, 376.0], [0, 380.0, 240.0], [0, 0, 1]])
+    out = oracle.undistort_points(uv, K, k, fisheye=True)
+    assert np.abs(out[:, 0] - xn).max() < 1e-3 and np.abs(out[:, 1] - yn).max() < 1e-3
+    # the centre maps to the origin exactly (theta_d <= 1e-8 keeps scale 1)
+    c = oracle.undistort_points(np.array([[376.0, 240.0]], np.float32), K, k, fisheye=True)
+    assert c[0, 0] == 0.0 and c[0, 1] == 0.0

@@ -42,7 +42,8 @@ enum {
     ORBX_ERR_HIP = -3,         /* a HIP runtime call failed (see orbx_last_error) */
     ORBX_ERR_CAPACITY = -4,    /* an output buffer is too small */
     ORBX_ERR_UNSUPPORTED = -5, /* geometry outside what the kernels support */
-    ORBX_ERR_STATE = -6        /* call order violated (e.g. no pyramid yet) */
+    ORBX_ERR_STATE = -6,       /* call order violated (e.g. no pyramid yet) */
+    ORBX_ERR_IO = -7           /* a file could not be opened, read or written */
 };
 
 const char *orbx_version(void);
@@ -254,6 +255,26 @@ int orbx_undistort_keypoints_device(orbx_ctx *ctx, const orbx_keypoint *d_kps_in
                                     int cap, int nframes, const double *K, const double *dist, int ndist,
                                     const double *R, const double *P, int p_cols, int fisheye,
                                     orbx_keypoint *d_kps_out);
+
+/* --- detection I/O (host only, no device needed) ------------------------------ */
+/* Frame::ExportToYML, src/Frame.cc:590-609: one cv::FileStorage YAML document with the keys
+ * nNextId, mnId, mTimeStamp, mK (3x3 float, skipped if NULL), mvKeys, mDescriptors (n x 32, dt u),
+ * mvKeysRight, mDescriptorsRight.  legacy_flat != 0 writes each keypoint list as one flat
+ * sequence of 7 numbers per keypoint (OpenCV before 3.3.1) instead of one flow sequence per
+ * keypoint; OpenCV's reader accepts both. */
+int orbx_detection_write_yaml(const char *path, double nNextId, double mnId, double mTimeStamp, const float *mK,
+                              const orbx_keypoint *keys, const uint8_t *desc, int n,
+                              const orbx_keypoint *keys_right, const uint8_t *desc_right, int n_right,
+                              int legacy_flat);
+/* KeyPointLog::ReadFromYAML, include/Util.hpp:400-449: reads mTimeStamp, mvKeys, mDescriptors,
+ * mvKeysRight, mDescriptorsRight.  With keys == NULL (keys_right == NULL) only the count is
+ * returned; ORBX_ERR_CAPACITY if a list is longer than its buffer.  A missing file gives
+ * ORBX_ERR_IO with *mTimeStamp = -1 and both counts 0, the state the reference leaves (:407-413). */
+int orbx_detection_read_yaml(const char *path, double *mTimeStamp,
+                             orbx_keypoint *keys, uint8_t *desc, int cap, int *n,
+                             orbx_keypoint *keys_right, uint8_t *desc_right, int cap_right, int *n_right);
+/* text of the last detection-I/O error on this thread */
+const char *orbx_io_last_error(void);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,126 @@
+"""Detection I/O wire format (Frame::ExportToYML, src/Frame.cc:590-609; KeyPointLog::ReadFromYAML,
+include/Util.hpp:400-449).  Host-only code of liborbx: runs without a GPU.  The reference holds no
+sample file and OpenCV is not installed, so the layout is pinned by (a) round trips, (b) the
+documented cv::FileStorage formatting rules checked on the text, and (c) a hand-written document in
+the layout OpenCV 3.4 emits, including its line wrapping."""
+import numpy as np
+import pytest
+
+from orb_slam_amd import KP_DTYPE, ExportToYML, KeyPointLog, OrbxError
+
+
+def _kps(n, seed):
+    rng = np.random.default_rng(seed)
+    k = np.zeros(n, KP_DTYPE)
+    k["x"] = (rng.random(n) * 752).astype(np.float32)
+    k["y"] = rng.integers(0, 480, n).astype(np.float32)        # integer-valued reals print as "123."
+    k["size"] = 31.0 * np.float32(1.2) ** rng.integers(0, 8, n)
+    k["angle"] = (rng.random(n) * 360).astype(np.float32)
+    k["response"] = rng.integers(7, 200, n)
+    k["octave"] = rng.integers(0, 8, n)
+    k["class_id"] = -1
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    return k, d
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_round_trip(tmp_path, flat):
+    kl, dl = _kps(1003, 1)
+    kr, dr = _kps(987, 2)
+    p = tmp_path / "frame.yml"
+    ts = 1403636579.763555527
+    ExportToYML(p, ts, kl, dl, kr, dr, mK=[[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], nNextId=7, mnId=6,
+                legacy_flat=flat)
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    assert log.mTimeStamp == ts                        # %.16e round-trips a double
+    assert np.array_equal(log.mvKeysLeft, kl) and np.array_equal(log.mvKeysRight, kr)   # %.8e round-trips a float
+    assert np.array_equal(log.mDiscLeft, dl) and np.array_equal(log.mDiscRight, dr)
+    text = p.read_text()
+    assert text.startswith("%YAML:1.0\n---\n")
+    assert max(len(l) for l in text.splitlines()) <= 80
+    assert "nNextId: 7.\n" in text and "mnId: 6.\n" in text
+    assert "mTimeStamp: 1.4036365797635555e+09\n" in text
+    assert "mK: !!opencv-matrix\n   rows: 3\n   cols: 3\n   dt: f\n   data: [ 4.58653992e+02, 0., 3.67214996e+02, 0., 4.57295990e+02,\n       2.48375000e+02, 0., 0., 1. ]\n" in text
+    assert "mDescriptors: !!opencv-matrix\n   rows: 1003\n   cols: 32\n   dt: u\n   data: [ " in text
+
+
+def test_empty_lists_and_missing_file(tmp_path):
+    kl, dl = _kps(5, 3)
+    p = tmp_path / "mono.yml"
+    ExportToYML(p, 12.5, kl, dl)                        # monocular: right lists empty
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    assert len(log.mvKeysRight) == 0 and log.mDiscRight.shape == (0, 32) and np.array_equal(log.mvKeysLeft, kl)
+    assert log.mTimeStamp == 12.5
+    # missing file: false, timestamp -1, lists cleared (include/Util.hpp:407-413)
+    assert not log.ReadFromYAML(tmp_path / "nope.yml")
+    assert log.mTimeStamp == -1 and len(log.mvKeysLeft) == 0 and len(log.mvKeysRight) == 0
+    # a file without the expected keys is an error, not an empty frame
+    q = tmp_path / "other.yml"
+    q.write_text("%YAML:1.0\n---\nfoo: 1\n")
+    with pytest.raises(OrbxError):
+        log.ReadFromYAML(q)
+
+
+OPENCV_STYLE = """%YAML:1.0
+---
+nNextId: 2.
+mnId: 1.
+mTimeStamp: 1.4036365798135555e+09
+mK: !!opencv-matrix
+   rows: 3
+   cols: 3
+   dt: f
+   data: [ 4.35204681e+02, 0., 3.67451721e+02, 0., 4.35204681e+02,
+       2.52200851e+02, 0., 0., 1. ]
+mvKeys:
+   - [ 1.23500000e+02, 45., 31., 2.70123413e+02, 57., 0, -1 ]
+   - [ 6.00480042e+02, 3.14400024e+02, 3.72000008e+01, 1.25000000e-01,
+       112., 1, -1 ]
+mDescriptors: !!opencv-matrix
+   rows: 2
+   cols: 32
+   dt: u
+   data: [ 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18,
+       19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 255, 254,
+       253, 252, 251, 250, 249, 248, 247, 246, 245, 244, 243, 242, 241,
+       240, 239, 238, 237, 236, 235, 234, 233, 232, 231, 230, 229, 228,
+       227, 226, 225, 224 ]
+mvKeysRight: [ 10., 20., 31., 90., 20., 0, -1 ]
+mDescriptorsRight: !!opencv-matrix
+   rows: 1
+   cols: 32
+   dt: u
+   data: [ 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+       0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7 ]
+"""
+
+
+def test_reads_opencv_layout(tmp_path):
+    p = tmp_path / "cv.yml"
+    p.write_text(OPENCV_STYLE)
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    assert log.mTimeStamp == 1403636579.8135555
+    assert len(log.mvKeysLeft) == 2 and len(log.mvKeysRight) == 1
+    k = log.mvKeysLeft
+    assert k["x"][0] == np.float32(123.5) and k["y"][0] == 45 and k["size"][0] == 31 and k["response"][0] == 57
+    assert k["x"][1] == np.float32(600.480042) and k["octave"][1] == 1 and k["class_id"][1] == -1
+    assert k["angle"][1] == np.float32(0.125) and k["response"][1] == 112
+    assert log.mDiscLeft[0].tolist() == list(range(1, 33)) and log.mDiscLeft[1].tolist() == list(range(255, 223, -1))
+    assert log.mvKeysRight["angle"][0] == 90 and log.mDiscRight[0, 31] == 7 and log.mDiscRight[0, :31].sum() == 0
+
+
+def test_extraction_output_survives_the_wire(tmp_path, oracle, euroc_left, euroc_right):
+    """what the tracker replays is bit-identical to what extraction produced"""
+    kl, dl = oracle.extract(euroc_left, literal=False)
+    kr, dr = oracle.extract(euroc_right, literal=False)
+    p = tmp_path / "euroc.yml"
+    ExportToYML(p, 1403636579.763555527, kl, dl, kr, dr)
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    for a, b in ((log.mvKeysLeft, kl), (log.mvKeysRight, kr)):
+        for f in KP_DTYPE.names:
+            assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(log.mDiscLeft, dl) and np.array_equal(log.mDiscRight, dr)

@@ -405,6 +405,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int pitch)
 }
 
 constexpr int kCellMax = 64;                       // largest cell side supported
+constexpr int kFastTileFixed = 48, kFastScoreFixed = 40;   // pitches of the specialised wave-per-cell kernel
 constexpr int kTilePitch = kCellMax + 6 + 6;       // LDS row pitch of the pixel tile (bytes, multiple of 4)
 constexpr int kScorePitch = kCellMax + 4;          // LDS row pitch of the score tile
 
@@ -526,7 +527,9 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // order.  Results are identical to k_fast_cells.
 // ---------------------------------------------------------------------------
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-template <int WAVES>
+// TPC / SPC: compile-time tile and score pitches (0 = take them from fl): with constants every
+// ring pixel is an immediate offset from one LDS address.
+template <int WAVES, int TPC = 0, int SPC = 0>
 __global__ __launch_bounds__(64 * WAVES) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
                                                         uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
 {
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_fast_cells_wave(const uint8_t* _
     uint32_t* s_tile = reinterpret_cast<uint32_t*>(wmem);
     uint8_t* s_score = wmem + fl.score_off;
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(wmem + fl.queue_off);
-    const int TP = fl.tile_pitch, SP = fl.score_pitch;
+    const int TP = TPC ? TPC : fl.tile_pitch, SP = SPC ? SPC : fl.score_pitch;
 
     const int lane = threadIdx.x & 63;
     const int bx = WAVES > 1 ? (int)(blockIdx.x * WAVES + (threadIdx.x >> 6)) : (int)blockIdx.x;
@@ -629,45 +632,58 @@ __global__ __launch_bounds__(64 * WAVES) void k_fast_cells_wave(const uint8_t* _
         }
     }
     WAVE_SYNC();
-    bool any = false;
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-        const int q = q0 + lane;
-        if (q < nq) {
-            const int i = s_queue[q];
-            const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
-            const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
-            const int s = sc[0];
-            if (s > 0 && s > sc[-1] && s > sc[1] && s > sc[-SP - 1] && s > sc[-SP] && s > sc[-SP + 1] &&
-                s > sc[SP - 1] && s > sc[SP] && s > sc[SP + 1]) {
-                s_queue[q] = (uint16_t)(i | 0x8000);
-                any = any || (s >= g.iniTh);
-            }
-        }
-    }
-    const bool use_ini = __ballot(any) != 0ull;
-    WAVE_SYNC();
+    // Strict 8-neighbour maxima.  Maxima that reach the initial threshold are emitted right
+    // here, in queue (= row-major) order: if the cell has any, they are its whole result
+    // (the first cv::FAST call of the reference found something).  Only a cell without one
+    // needs the second sweep, which emits every flagged maximum (the minThFAST call).
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
     int base = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
-        bool keep = false;
+        bool hit = false;
         int py = 0, px = 0, s = 0;
         if (q < nq) {
-            const int e = s_queue[q];
-            if (e & 0x8000) {
-                const int i = e & 0x7fff;
-                py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
-                px = i - __mul24(py, cw);
-                s = s_score[(py + 1) * SP + px + 1];
-                keep = !use_ini || s >= g.iniTh;
+            const int i = s_queue[q];
+            py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
+            px = i - __mul24(py, cw);
+            const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
+            s = sc[0];
+            if (s > 0 && s > sc[-1] && s > sc[1] && s > sc[-SP - 1] && s > sc[-SP] && s > sc[-SP + 1] &&
+                s > sc[SP - 1] && s > sc[SP] && s > sc[SP + 1]) {
+                s_queue[q] = (uint16_t)(i | 0x8000);
+                hit = s >= g.iniTh;
             }
         }
-        const unsigned long long bal = __ballot(keep);
-        if (keep) {
+        const unsigned long long bal = __ballot(hit);
+        if (hit) {
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
             if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
         }
         base += __popcll(bal);
+    }
+    if (base == 0) {
+        WAVE_SYNC();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int q = q0 + lane;
+            bool keep = false;
+            int py = 0, px = 0, s = 0;
+            if (q < nq) {
+                const int e = s_queue[q];
+                if (e & 0x8000) {
+                    const int i = e & 0x7fff;
+                    py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
+                    px = i - __mul24(py, cw);
+                    s = s_score[(py + 1) * SP + px + 1];
+                    keep = true;
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+            }
+            base += __popcll(bal);
+        }
     }
     if (lane == 0) *count_out = min(base, L.cell_cap);
 }
@@ -1106,6 +1122,9 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
         if (g.lv[l].width > 0) { wc = std::max(wc, g.lv[l].wCell); hc = std::max(hc, g.lv[l].hCell); }
     fl.tile_pitch = (wc + 6 + 3 + 3) & ~3;                 // + up to 3 bytes of dword misalignment
     fl.score_pitch = (wc + 2 + 3) & ~3;
+    // the usual 30-pixel cells fit the pitches the specialised kernel is compiled for
+    fl.fixed_pitch = fl.tile_pitch <= kFastTileFixed && fl.score_pitch <= kFastScoreFixed && !getenv("ORBX_FAST_VAR_PITCH");
+    if (fl.fixed_pitch) { fl.tile_pitch = kFastTileFixed; fl.score_pitch = kFastScoreFixed; }
     const int tile_bytes = fl.tile_pitch * (hc + 6);
     const int score_bytes = fl.score_pitch * (hc + 2);
     fl.score_off = (tile_bytes + 15) & ~15;
@@ -1126,7 +1145,11 @@ void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLd
         hipLaunchKernelGGL(k_fast_cells_wave<4>, grid, dim3(256), (size_t)fl.total * 4, s, pyr, g, fl, cell_cand, cell_count);
     } else {
         dim3 grid(padded, nframes);
-        hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
+        if (fl.fixed_pitch)
+            hipLaunchKernelGGL((k_fast_cells_wave<1, kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr,
+                               g, fl, cell_cand, cell_count);
+        else
+            hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
     }
 }
 

@@ -529,30 +529,35 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // TPC / SPC: compile-time tile and score pitches (0 = take them from fl): with constants every
 // ring pixel is an immediate offset from one LDS address.
-template <int WAVES, int TPC = 0, int SPC = 0>
-__global__ __launch_bounds__(64 * WAVES) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
-                                                        uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
+template <int TPC = 0, int SPC = 0>
+__global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
+                                                        uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
+                                                        int frame_per_xcd, unsigned long long rcp_ncells, int nframes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // every wavefront of the workgroup handles a cell of its own in its own LDS slice; nothing is
-    // shared between wavefronts, so wave-level fences replace workgroup barriers
-    unsigned char* wmem = smem + (WAVES > 1 ? (threadIdx.x >> 6) * fl.total : 0);
-    uint32_t* s_tile = reinterpret_cast<uint32_t*>(wmem);
-    uint8_t* s_score = wmem + fl.score_off;
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(wmem + fl.queue_off);
+    // one wavefront = one workgroup = one cell: wave-level fences replace workgroup barriers
+    uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);
+    uint8_t* s_score = smem + fl.score_off;
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(smem + fl.queue_off);
     const int TP = TPC ? TPC : fl.tile_pitch, SP = SPC ? SPC : fl.score_pitch;
 
-    const int lane = threadIdx.x & 63;
-    const int bx = WAVES > 1 ? (int)(blockIdx.x * WAVES + (threadIdx.x >> 6)) : (int)blockIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2); the grid is padded
-    // to a multiple of 64 cells per frame, so blocks x, x+8, x+16, ... share an XCD.  Give them
-    // neighbouring cells: neighbouring tiles share their 3-pixel rings and cache lines.
-    // Groups of 8 consecutive cells go to one XCD, groups round-robin over the XCDs (this also
-    // spreads the more expensive low-level cells evenly).
-    const int seq = (int)(blockIdx.x >> 3) * WAVES + (WAVES > 1 ? (int)(threadIdx.x >> 6) : 0);   // position in this XCD's sequence
-    const int cell = fl.xcd_map ? (((seq >> 3) << 3) + (int)(blockIdx.x & 7)) * 8 + (seq & 7) : bx;
-    const int f = blockIdx.y;
-    if (cell >= g.ncells) return;
+    const int lane = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Neighbouring
+    // tiles share their 3-pixel rings and cache lines, so a large batch gives every frame to one
+    // XCD (1-D grid, block b -> XCD b % 8 -> frame 8 * (b / 8 / ncells) + b % 8): 2.8x less
+    // fetch than cells scattered over all L2s.  Small batches use the plain (cell, frame) grid
+    // so that one frame still spreads over the whole device.
+    int cell, f;
+    if (frame_per_xcd) {
+        const uint32_t seq = blockIdx.x >> 3;
+        const uint32_t fq = (uint32_t)(((unsigned long long)seq * rcp_ncells) >> 40);    // seq / ncells
+        cell = (int)(seq - fq * (uint32_t)g.ncells);
+        f = (int)(fq * 8 + (blockIdx.x & 7));
+        if (f >= nframes) return;
+    } else {
+        cell = blockIdx.x;
+        f = blockIdx.y;
+    }
     int level = 0;
 #pragma unroll
     for (int l = 1; l < kMaxLevels; l++)
@@ -1131,26 +1136,23 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
     fl.total = fl.queue_off + 2 * wc * hc + 16;
     fl.total = (fl.total + 15) & ~15;
-    fl.xcd_map = getenv("ORBX_FAST_NO_XCD_MAP") ? 0 : 1;
 }
 
 void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
                             int* cell_count, int nframes, hipStream_t s)
 {
     if (g.ncells == 0) return;
-    const int padded = fl.xcd_map ? ((g.ncells + 63) & ~63) : g.ncells;
-    static const int waves = getenv("ORBX_FAST_WAVES") ? atoi(getenv("ORBX_FAST_WAVES")) : 1;
-    if (waves == 4 && (size_t)fl.total * 4 <= 64 * 1024) {
-        dim3 grid((padded + 3) / 4, nframes);
-        hipLaunchKernelGGL(k_fast_cells_wave<4>, grid, dim3(256), (size_t)fl.total * 4, s, pyr, g, fl, cell_cand, cell_count);
-    } else {
-        dim3 grid(padded, nframes);
-        if (fl.fixed_pitch)
-            hipLaunchKernelGGL((k_fast_cells_wave<1, kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr,
-                               g, fl, cell_cand, cell_count);
-        else
-            hipLaunchKernelGGL(k_fast_cells_wave<1>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count);
-    }
+    static const int env_map = getenv("ORBX_FAST_XCD_MAP") ? atoi(getenv("ORBX_FAST_XCD_MAP")) : -1;
+    // one XCD per frame needs enough frames to keep all 8 busy
+    const int per_xcd = env_map >= 0 ? env_map : (nframes >= 32);
+    const unsigned long long rcp = ((1ull << 40) + (unsigned long long)g.ncells - 1) / (unsigned long long)g.ncells;
+    dim3 grid = per_xcd ? dim3((unsigned)(8 * g.ncells * ((nframes + 7) / 8))) : dim3(g.ncells, nframes);
+    if (fl.fixed_pitch)
+        hipLaunchKernelGGL((k_fast_cells_wave<kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr,
+                           g, fl, cell_cand, cell_count, per_xcd, rcp, nframes);
+    else
+        hipLaunchKernelGGL(k_fast_cells_wave<>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count,
+                           per_xcd, rcp, nframes);
 }
 
 size_t quadtree_lds_bytes(int max_nodes) { return quadtree_fixed_lds(max_nodes); }
@@ -1213,10 +1215,11 @@ __device__ __forceinline__ void sincos_turn(double x, double* sn, double* cs)
     *cs = ((k + 1) & 2) ? -c1 : c1;
 }
 
-// 32 lanes per keypoint, 8 keypoints per workgroup.  1-D grid of 8 * nbx * ceil(frames/8)
-// workgroups.  Workgroups are dealt round-robin over the 8 XCDs, and the patches of one frame's
-// keypoints overlap heavily, so every frame is given to one XCD (frame f -> XCD f % 8): its
-// planes are then fetched into one L2 once instead of into all eight.
+// 32 lanes per keypoint, 8 keypoints per workgroup.  Workgroups are dealt round-robin over the
+// 8 XCDs, and the patches of one frame's keypoints overlap heavily, so a large batch runs on a 1-D
+// grid of 8 * nbx * ceil(frames/8) workgroups that gives every frame to one XCD (frame f -> XCD
+// f % 8): its planes are then fetched into one L2 once instead of into all eight.  Small batches
+// use the plain (block, frame) grid.
 // Descriptor sampling window: the rotated test points stay within 18 pixels of the keypoint
 // (pattern coordinates are within +-13, 13 * sqrt(2) = 18.4), so a 37-row window of 10 aligned
 // dwords per row (37 columns + up to 3 bytes of misalignment) holds every sample.
@@ -1229,7 +1232,7 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
                                                      const uint2* __restrict__ kp_stage,
                                                      const int* __restrict__ level_count,
                                                      orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                     int cap, int* __restrict__ n_out, int nbx, int nframes)
+                                                     int cap, int* __restrict__ n_out, int nbx, int nframes, int frame_per_xcd)
 {
     // the 256 test pairs as floats, s_pat[j * 32 + byte] = (x0, y0, x1, y1) of pair 8 * byte + j
     __shared__ float4 s_pat[256];
@@ -1241,10 +1244,17 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     }
     __syncthreads();
 
-    const int seq = blockIdx.x >> 3;                  // position in this XCD's sequence
-    const int fq = seq / nbx, bx = seq - fq * nbx;
-    const int f = fq * 8 + (int)(blockIdx.x & 7);
-    if (f >= nframes) return;
+    int f, bx;
+    if (frame_per_xcd) {
+        const int seq = blockIdx.x >> 3;              // position in this XCD's sequence
+        const int fq = seq / nbx;
+        bx = seq - fq * nbx;
+        f = fq * 8 + (int)(blockIdx.x & 7);
+        if (f >= nframes) return;
+    } else {                                          // small batch: plain (block, frame) grid
+        bx = blockIdx.x;
+        f = blockIdx.y;
+    }
     const int slot = bx * 8 + (tid >> 5);
     const int* lc = level_count + f * kMaxLevels;
     int level = -1, k = 0, prefix = 0, total = 0;
@@ -1493,9 +1503,10 @@ void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* b
                         int nframes, hipStream_t s)
 {
     const int nbx = g.kp_per_frame > 0 ? (g.kp_per_frame + 7) / 8 : 1;
-    dim3 grid((unsigned)(8 * nbx * ((nframes + 7) / 8)));
+    const int per_xcd = nframes >= 32;                // one XCD per frame needs enough frames to keep all 8 busy
+    dim3 grid = per_xcd ? dim3((unsigned)(8 * nbx * ((nframes + 7) / 8))) : dim3(nbx, nframes);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, g, pyr, blur, reinterpret_cast<const uint2*>(kp_stage),
-                       level_count, out_kps, out_desc, cap, n_out, nbx, nframes);
+                       level_count, out_kps, out_desc, cap, n_out, nbx, nframes, per_xcd);
 }
 
 } // namespace orbx

@@ -25,7 +25,6 @@ struct FastLds {
     int score_off, queue_off;      // byte offsets inside the dynamic LDS block
     int total;                     // bytes of dynamic LDS per workgroup
     int fixed_pitch;               // 1: the pitches are the compile-time ones of the specialised kernel
-    int xcd_map;                   // 1: groups of 8 neighbouring cells share an XCD (less HBM traffic)
 };
 
 struct ScaleTab { float v[kMaxLevels]; };

@@ -612,12 +612,13 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         bool pass = false;
         if (i < npix) {
             const uint8_t* c = tile8 + addr;
-            const int v = c[0], hi = v + t, lo = v - t;
+            // two adjacent compass points brighter than v + t  <=>  min(max(p0,p8), max(p4,p12)) - v > t
+            // (every pair of one vertical and one horizontal compass point is adjacent); likewise darker
+            const int v = c[0];
             const int p0 = c[TP3], p4 = c[3], p8 = c[-TP3], p12 = c[-3];
-            const bool b0 = p0 > hi, b4 = p4 > hi, b8 = p8 > hi, b12 = p12 > hi;
-            const bool d0 = p0 < lo, d4 = p4 < lo, d8 = p8 < lo, d12 = p12 < lo;
-            pass = (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0) ||
-                   (d0 && d4) || (d4 && d8) || (d8 && d12) || (d12 && d0);
+            const int br = min(max(p0, p8), max(p4, p12)) - v;
+            const int dk = v - max(min(p0, p8), min(p4, p12));
+            pass = max(br, dk) > t;
         }
         px += r64;
         addr += adv;

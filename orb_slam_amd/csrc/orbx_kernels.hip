@@ -654,8 +654,10 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             px = i - __mul24(py, cw);
             const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
             s = sc[0];
-            if (s > 0 && s > sc[-1] && s > sc[1] && s > sc[-SP - 1] && s > sc[-SP] && s > sc[-SP + 1] &&
-                s > sc[SP - 1] && s > sc[SP] && s > sc[SP + 1]) {
+            const int m0 = max(max((int)sc[-SP - 1], (int)sc[-SP]), (int)sc[-SP + 1]);
+            const int m1 = max(max((int)sc[SP - 1], (int)sc[SP]), (int)sc[SP + 1]);
+            const int m2 = max(max((int)sc[-1], (int)sc[1]), 0);
+            if (s > max(max(m0, m1), m2)) {            // strict maximum of its 8 neighbours, and non-zero
                 s_queue[q] = (uint16_t)(i | 0x8000);
                 hit = s >= g.iniTh;
             }

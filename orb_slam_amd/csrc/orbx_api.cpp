@@ -64,7 +64,7 @@ struct orbx_ctx {
     TileMap tm;
     SlideMap blur_map;
     FastLds fast_lds;
-    DevBuf xtab, ytab, xtab4, ytab2;
+    DevBuf xtab, ytab, xtab4, ytab2, fast_cells;
 
     // per-batch working set
     int cap_frames = 0;
@@ -148,6 +148,9 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     HIPCHECK(c, c->ytab2.ensure(rt.ytab2.size() * sizeof(YTab2)));
     HIPCHECK(c, hipMemcpyAsync(c->xtab4.p, rt.xtab4.data(), rt.xtab4.size() * sizeof(XTab4), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipMemcpyAsync(c->ytab2.p, rt.ytab2.data(), rt.ytab2.size() * sizeof(YTab2), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, c->fast_cells.ensure(rt.fast_cells.size() * sizeof(FastCell) + 32));
+    if (!rt.fast_cells.empty())
+        HIPCHECK(c, hipMemcpyAsync(c->fast_cells.p, rt.fast_cells.data(), rt.fast_cells.size() * sizeof(FastCell), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));   // the tables are stack-owned
     c->g = g;
     make_blur_tilemap(c->g, c->tm);
@@ -228,7 +231,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     }
     t0(ST_FAST, s);
     if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
-    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->fast_cells.as<FastCell>(), c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
     t1(ST_FAST, s);
     // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
     // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
@@ -323,7 +326,7 @@ void orbx_destroy(orbx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
+    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],

@@ -67,4 +67,20 @@ struct XTab4 { uint32_t base; uint32_t sel[4]; uint32_t a01[4]; };   // 36 bytes
 // (pointing at source image column 0) and the vertical weights.
 struct YTab2 { uint32_t off0, off1; int16_t b0, b1; };               // 12 bytes
 
+// Everything the per-cell FAST kernel needs to know about one cell of one frame geometry, so
+// that a wavefront starts with one 32-byte scalar load instead of a level search and divisions.
+struct FastCell {
+    uint32_t src_off;    // byte offset inside a frame of the tile's first dword (3-pixel ring included)
+    uint32_t cand_off;   // first candidate slot of this cell inside a frame
+    uint32_t rcp_cw;     // ceil(2^18 / cw): i / cw for i < 2^12
+    uint32_t rcp_ndw;    // ceil(2^16 / ndw): i / ndw for i < 2^12
+    uint16_t pitch;      // plane pitch
+    uint16_t cell_cap;   // candidate slots
+    uint8_t cw, ch;      // tested area (0: empty cell)
+    uint8_t ox;          // bytes between the tile's first dword and its first pixel
+    uint8_t ndw;         // dwords per tile row
+    uint32_t pad[2];
+};
+static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8");
+
 } // namespace orbx

@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 template <int TPC = 0, int SPC = 0>
 __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
                                                         uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
-                                                        int frame_per_xcd, unsigned long long rcp_ncells, int nframes)
+                                                        const FastCell* __restrict__ cells, int frame_per_xcd, unsigned long long rcp_ncells, int nframes)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // one wavefront = one workgroup = one cell: wave-level fences replace workgroup barriers
@@ -558,32 +558,19 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         cell = blockIdx.x;
         f = blockIdx.y;
     }
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < kMaxLevels; l++)
-        if (l < g.nlevels && g.lv[l].width > 0 && cell >= g.lv[l].cell_base) level = l;
-    const LevelGeom& L = g.lv[level];
-    const int cl = cell - L.cell_base;
-    const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
-    const int tx0 = cj * L.wCell + 3, tx1 = min((cj + 1) * L.wCell + 3, L.width - 3);
-    const int ty0 = ci * L.hCell + 3, ty1 = min((ci + 1) * L.hCell + 3, L.height - 3);
-    const int cw = tx1 - tx0, ch = ty1 - ty0;
+    const FastCell fc = cells[cell];                 // wave-uniform: one scalar load
+    const int cw = fc.cw, ch = fc.ch, ox = fc.ox, ndw = fc.ndw, pitch = fc.pitch, cell_cap = fc.cell_cap;
     int* count_out = cell_count + (size_t)f * g.ncells + cell;
-    if (cw <= 0 || ch <= 0) {
+    if (cw == 0) {
         if (lane == 0) *count_out = 0;
         return;
     }
-    const uint8_t* plane = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off;
-    const int pcol0 = kPadX + kDetBorder + tx0 - 3;
-    const int prow0 = kPadY + kDetBorder + ty0 - 3;
-    const int acol0 = pcol0 & ~3, ox = pcol0 - acol0;
-    const int ndw = (ox + cw + 6 + 3) >> 2;
+    const uint8_t* src = pyr + (size_t)f * g.pyr_frame_bytes + fc.src_off;
     const int th = ch + 6;
-    const uint32_t rcp_ndw = (65536u + ndw - 1) / ndw;          // i / ndw for i < 2^12, ndw <= 20
+    const uint32_t rcp_ndw = fc.rcp_ndw;                        // i / ndw for i < 2^12, ndw <= 20
     for (int i = lane; i < th * ndw; i += 64) {
         int r = (int)(((uint32_t)i * rcp_ndw) >> 16), c = i - r * ndw;
-        s_tile[r * (TP >> 2) + c] =
-            *reinterpret_cast<const uint32_t*>(plane + (size_t)(prow0 + r) * L.pitch + acol0 + 4 * c);
+        s_tile[r * (TP >> 2) + c] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(r * pitch + 4 * c));
     }
     {
         uint32_t* sc32 = reinterpret_cast<uint32_t*>(s_score);
@@ -593,7 +580,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
 
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
     const int npix = cw * ch;
-    const uint32_t rcp_cw = ((1u << 18) + cw - 1) / cw;          // i / cw for i < 2^12, cw <= 64
+    const uint32_t rcp_cw = fc.rcp_cw;                           // i / cw for i < 2^12, cw <= 64
     const int t = g.minTh;
     int nq = 0;
     // the lane's pixel advances by 64 positions per round: keep its column and tile offset
@@ -642,7 +629,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     // here, in queue (= row-major) order: if the cell has any, they are its whole result
     // (the first cv::FAST call of the reference found something).  Only a cell without one
     // needs the second sweep, which emits every flagged maximum (the minThFAST call).
-    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
+    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
     int base = 0;
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
@@ -665,7 +652,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         const unsigned long long bal = __ballot(hit);
         if (hit) {
             const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+            if (pos < cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
         }
         base += __popcll(bal);
     }
@@ -688,12 +675,12 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             const unsigned long long bal = __ballot(keep);
             if (keep) {
                 const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-                if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+                if (pos < cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
             }
             base += __popcll(bal);
         }
     }
-    if (lane == 0) *count_out = min(base, L.cell_cap);
+    if (lane == 0) *count_out = min(base, cell_cap);
 }
 
 #undef WAVE_SYNC
@@ -1141,8 +1128,8 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     fl.total = (fl.total + 15) & ~15;
 }
 
-void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
-                            int* cell_count, int nframes, hipStream_t s)
+void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, const FastCell* cells,
+                            uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s)
 {
     if (g.ncells == 0) return;
     static const int env_map = getenv("ORBX_FAST_XCD_MAP") ? atoi(getenv("ORBX_FAST_XCD_MAP")) : -1;
@@ -1152,10 +1139,10 @@ void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLd
     dim3 grid = per_xcd ? dim3((unsigned)(8 * g.ncells * ((nframes + 7) / 8))) : dim3(g.ncells, nframes);
     if (fl.fixed_pitch)
         hipLaunchKernelGGL((k_fast_cells_wave<kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr,
-                           g, fl, cell_cand, cell_count, per_xcd, rcp, nframes);
+                           g, fl, cell_cand, cell_count, cells, per_xcd, rcp, nframes);
     else
         hipLaunchKernelGGL(k_fast_cells_wave<>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count,
-                           per_xcd, rcp, nframes);
+                           cells, per_xcd, rcp, nframes);
 }
 
 size_t quadtree_lds_bytes(int max_nodes) { return quadtree_fixed_lds(max_nodes); }

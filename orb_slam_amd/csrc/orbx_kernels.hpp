@@ -45,7 +45,7 @@ void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, co
 void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
                        int nframes, hipStream_t s);
 void make_fast_lds(const FrameGeom& g, FastLds& fl);
-void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, uint32_t* cell_cand,
+void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, const FastCell* cells, uint32_t* cell_cand,
                             int* cell_count, int nframes, hipStream_t s);
 size_t quadtree_lds_bytes(int max_nodes);
 int quadtree_prepare(int max_nodes);

@@ -223,6 +223,33 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
     }
     if (pyr > 0xFFFFFFFFull || cand > 0x7FFFFFFFull) { *msg = "frame too large"; return ORBX_ERR_UNSUPPORTED; }
     g.ncells = cells;
+    // per-cell constants of the FAST kernel (tested areas tile [3, width-3) x [3, height-3))
+    tabs.fast_cells.assign((size_t)cells, FastCell{});
+    for (int l = 0; l < p.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        if (L.width <= 0) continue;
+        for (int cl = 0; cl < L.nCols * L.nRows; cl++) {
+            FastCell& fc = tabs.fast_cells[(size_t)L.cell_base + cl];
+            const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
+            const int tx0 = cj * L.wCell + 3, tx1 = std::min((cj + 1) * L.wCell + 3, L.width - 3);
+            const int ty0 = ci * L.hCell + 3, ty1 = std::min((ci + 1) * L.hCell + 3, L.height - 3);
+            const int cw = std::max(tx1 - tx0, 0), ch = std::max(ty1 - ty0, 0);
+            const int pcol0 = kPadX + kDetBorder + tx0 - 3, prow0 = kPadY + kDetBorder + ty0 - 3;
+            const int acol0 = pcol0 & ~3, ox = pcol0 - acol0;
+            const int ndw = (ox + cw + 6 + 3) >> 2;
+            fc.cand_off = L.cand_base + (uint32_t)cl * (uint32_t)L.cell_cap;
+            fc.cell_cap = (uint16_t)L.cell_cap;
+            fc.pitch = (uint16_t)L.pitch;
+            if (cw == 0 || ch == 0) continue;      // cw = ch = 0: the kernel only writes a zero count
+            fc.src_off = L.plane_off + (uint32_t)prow0 * (uint32_t)L.pitch + (uint32_t)acol0;
+            fc.rcp_cw = ((1u << 18) + cw - 1) / cw;
+            fc.rcp_ndw = (65536u + ndw - 1) / ndw;
+            fc.cw = (uint8_t)cw;
+            fc.ch = (uint8_t)ch;
+            fc.ox = (uint8_t)ox;
+            fc.ndw = (uint8_t)ndw;
+        }
+    }
     g.pyr_frame_bytes = (uint32_t)pyr;
     g.cand_per_frame = (uint32_t)cand;
     g.keys_per_frame = (uint32_t)cand;

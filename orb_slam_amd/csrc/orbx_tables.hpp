@@ -28,6 +28,7 @@ struct ResizeTables {
     std::vector<YTab> ytab;
     std::vector<XTab4> xtab4;
     std::vector<YTab2> ytab2;
+    std::vector<FastCell> fast_cells;   // [g.ncells]
 };
 int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& t, const char** msg);
 

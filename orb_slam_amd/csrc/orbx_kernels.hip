@@ -313,7 +313,8 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     const int flat = (item - sm.base[level]) * 64 + lane;
     const int ndw = sm.ndw[level];
     if (flat >= ndw * sm.nrb[level]) return;
-    const int rb = flat / ndw, dw = flat - rb * ndw;     // band, dword column inside the level image
+    const int rb = ndw == 1 ? flat : (int)__umulhi((uint32_t)flat, sm.rcp_ndw[level]);   // band
+    const int dw = flat - rb * ndw;                      // dword column inside the level image
     const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
     const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
     const uint8_t* src = pyr + fbase + (size_t)(kPadY + y0 - 3) * L.pitch + kPadX + 4 * dw - 4;
@@ -1413,11 +1414,14 @@ void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
     for (int l = 0; l < kMaxLevels; l++) {
         sm.base[l] = base;
         sm.ndw[l] = 1;
+        sm.rcp_ndw[l] = 0;
         sm.nrb[l] = 0;
         sm.rows[l] = 1;
         if (l < g.nlevels && g.lv[l].w > 0 && g.lv[l].h > 0) {
             const int nrb = (g.lv[l].h + target_rows - 1) / target_rows;
             sm.ndw[l] = (g.lv[l].w + 3) / 4;
+            // exact for flat < 2^32 / ndw, far above bands * ndw (ndw = 1 is handled in the kernel)
+            sm.rcp_ndw[l] = sm.ndw[l] > 1 ? (uint32_t)(((1ull << 32) + sm.ndw[l] - 1) / sm.ndw[l]) : 0u;
             sm.nrb[l] = nrb;
             sm.rows[l] = (g.lv[l].h + nrb - 1) / nrb;      // <= h
             base += (sm.ndw[l] * nrb + 63) / 64;

@@ -15,6 +15,7 @@ struct TileMap {
 struct SlideMap {
     int base[kMaxLevels + 1];   // first item of each level; [kMaxLevels] = total
     int ndw[kMaxLevels];        // dword columns of the level image
+    uint32_t rcp_ndw[kMaxLevels];   // ceil(2^32 / ndw): flat / ndw by one mul_hi
     int nrb[kMaxLevels];        // row bands per level
     int rows[kMaxLevels];       // rows per band (every band has this many; the last one is shifted up to fit)
 };

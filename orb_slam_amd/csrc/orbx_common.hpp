@@ -79,7 +79,9 @@ struct FastCell {
     uint8_t cw, ch;      // tested area (0: empty cell)
     uint8_t ox;          // bytes between the tile's first dword and its first pixel
     uint8_t ndw;         // dwords per tile row
-    uint32_t pad[2];
+    uint8_t rpr;         // whole cell rows one 64-lane round of the pretest covers (0: flat pixel order instead)
+    uint8_t pad8[3];
+    uint32_t pad;
 };
 static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8");
 

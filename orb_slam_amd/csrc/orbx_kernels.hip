@@ -584,36 +584,63 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     const uint32_t rcp_cw = fc.rcp_cw;                           // i / cw for i < 2^12, cw <= 64
     const int t = g.minTh;
     int nq = 0;
-    // the lane's pixel advances by 64 positions per round: keep its column and tile offset
-    // incrementally instead of dividing every round
-    const int q64 = (int)(__umul24(64u, rcp_cw) >> 18), r64 = 64 - q64 * cw;     // 64 = q64*cw + r64
-    const int adv = q64 * TP + r64, wrap = TP - cw, TP3 = 3 * TP;
-    int px;
-    int addr;
-    {
-        const int py0 = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18);
-        px = lane - __mul24(py0, cw);
-        addr = __mul24(py0 + 3, TP) + px + 3 + ox;
-    }
-    for (int i0 = 0; i0 < npix; i0 += 64) {
-        const int i = i0 + lane;
-        bool pass = false;
-        if (i < npix) {
-            const uint8_t* c = tile8 + addr;
-            // two adjacent compass points brighter than v + t  <=>  min(max(p0,p8), max(p4,p12)) - v > t
-            // (every pair of one vertical and one horizontal compass point is adjacent); likewise darker
-            const int v = c[0];
-            const int p0 = c[TP3], p4 = c[3], p8 = c[-TP3], p12 = c[-3];
-            const int br = min(max(p0, p8), max(p4, p12)) - v;
-            const int dk = v - max(min(p0, p8), min(p4, p12));
-            pass = max(br, dk) > t;
+    const int TP3 = 3 * TP;
+    if (fc.rpr) {
+        // whole rows per round: lane = (row r of the round, column c); a round advances every lane
+        // by rpr rows, i.e. by constants.  Lanes past rpr * cw idle (at most 12 of 64).
+        const int R = fc.rpr;
+        const int r = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18), c = lane - __mul24(r, cw);
+        const int step_addr = R * TP, step_idx = R * cw;
+        int addr = __mul24(r + 3, TP) + c + 3 + ox;
+        int idx = r < R ? lane : npix;               // pixel index row * cw + c; idle lanes never pass the bound
+        for (int y0 = 0; y0 < ch; y0 += R) {
+            bool pass = false;
+            if (idx < npix) {
+                const uint8_t* p = tile8 + addr;
+                const int v = p[0];
+                const int p0 = p[TP3], p4 = p[3], p8 = p[-TP3], p12 = p[-3];
+                const int br = min(max(p0, p8), max(p4, p12)) - v;
+                const int dk = v - max(min(p0, p8), min(p4, p12));
+                pass = max(br, dk) > t;
+            }
+            const unsigned long long bal = __ballot(pass);
+            if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+            nq += __popcll(bal);
+            addr += step_addr;
+            idx += step_idx;
         }
-        px += r64;
-        addr += adv;
-        if (px >= cw) { px -= cw; addr += wrap; }
-        const unsigned long long bal = __ballot(pass);
-        if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
-        nq += __popcll(bal);
+    } else {
+        // the lane's pixel advances by 64 positions per round: keep its column and tile offset
+        // incrementally instead of dividing every round
+        const int q64 = (int)(__umul24(64u, rcp_cw) >> 18), r64 = 64 - q64 * cw;     // 64 = q64*cw + r64
+        const int adv = q64 * TP + r64, wrap = TP - cw;
+        int px;
+        int addr;
+        {
+            const int py0 = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18);
+            px = lane - __mul24(py0, cw);
+            addr = __mul24(py0 + 3, TP) + px + 3 + ox;
+        }
+        for (int i0 = 0; i0 < npix; i0 += 64) {
+            const int i = i0 + lane;
+            bool pass = false;
+            if (i < npix) {
+                const uint8_t* c = tile8 + addr;
+                // two adjacent compass points brighter than v + t  <=>  min(max(p0,p8), max(p4,p12)) - v > t
+                // (every pair of one vertical and one horizontal compass point is adjacent); likewise darker
+                const int v = c[0];
+                const int p0 = c[TP3], p4 = c[3], p8 = c[-TP3], p12 = c[-3];
+                const int br = min(max(p0, p8), max(p4, p12)) - v;
+                const int dk = v - max(min(p0, p8), min(p4, p12));
+                pass = max(br, dk) > t;
+            }
+            px += r64;
+            addr += adv;
+            if (px >= cw) { px -= cw; addr += wrap; }
+            const unsigned long long bal = __ballot(pass);
+            if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
+            nq += __popcll(bal);
+        }
     }
     WAVE_SYNC();
     for (int q0 = 0; q0 < nq; q0 += 64) {

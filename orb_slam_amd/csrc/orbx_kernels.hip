@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void k_pyr_resize(uint8_t* __restrict__ pyr, F
 // v_perm_b32 pulls each column's (left, right) pair out as two u16 and
 // v_dot2_u32_u16 applies the two horizontal weights.  No LDS, no barriers.
 struct __attribute__((packed)) Unaligned8 { uint32_t lo, hi; };
+struct Aligned12 { uint32_t a, b, c; };
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint32_t a01)
@@ -153,13 +154,18 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
                                             int dwc, int r0, int r1)
 {
     const XTab4 x = xtab[L.xtab4_off + dwc];
-    const uint8_t* src = frame + P.plane_off + x.base;
+    // The 8 source bytes of this lane start at an arbitrary byte; a misaligned vector load is split
+    // into many cache accesses, so fetch the 3 aligned dwords around them and shift (row offsets,
+    // plane offsets and pitches are multiples of 4: the misalignment is the lane's constant).
+    const uint32_t shx = x.base & 3u;
+    const uint8_t* src = frame + P.plane_off + (x.base & ~3u);
     uint8_t* dst = frame + L.plane_off + 4 * dwc;
     const YTab2* yt = ytab + L.ytab2_off;
     const int rlast = L.rows - 1;
     // groups of 4 rows, all 8 loads issued before the arithmetic; a group that runs past the
     // plane repeats its last row (same bytes written again)
     for (int rg = r0; rg < r1; rg += 4) {
+        Aligned12 t0[4], t1[4];
         Unaligned8 s0[4], s1[4];
         YTab2 y[4];
         int rr[4];
@@ -167,8 +173,15 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
         for (int k = 0; k < 4; k++) {
             rr[k] = min(rg + k, rlast);
             y[k] = yt[rr[k]];
-            s0[k] = *reinterpret_cast<const Unaligned8*>(src + y[k].off0);
-            s1[k] = *reinterpret_cast<const Unaligned8*>(src + y[k].off1);
+            t0[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off0);
+            t1[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            s0[k].lo = __builtin_amdgcn_alignbyte(t0[k].b, t0[k].a, shx);
+            s0[k].hi = __builtin_amdgcn_alignbyte(t0[k].c, t0[k].b, shx);
+            s1[k].lo = __builtin_amdgcn_alignbyte(t1[k].b, t1[k].a, shx);
+            s1[k].hi = __builtin_amdgcn_alignbyte(t1[k].c, t1[k].b, shx);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {

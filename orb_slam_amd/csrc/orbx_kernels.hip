@@ -162,40 +162,58 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
     uint8_t* dst = frame + L.plane_off + 4 * dwc;
     const YTab2* yt = ytab + L.ytab2_off;
     const int rlast = L.rows - 1;
-    // groups of 4 rows, all 8 loads issued before the arithmetic; a group that runs past the
-    // plane repeats its last row (same bytes written again)
+    // Groups of 4 rows, all loads issued before the arithmetic; a group that runs past the plane
+    // repeats its last row (same bytes written again).  Successive destination rows mostly share
+    // a source row (the second one of row r is the first one of row r+1 five times out of six at
+    // scale 1.2): its horizontal sums are kept instead of being loaded and computed again.  The
+    // row numbers are wave-uniform, so these decisions are scalar branches.
+    uint32_t hp[4] = {0, 0, 0, 0};                  // horizontal sums of the last second source row
+    uint32_t prev_off = 0xffffffffu;                // its offset
     for (int rg = r0; rg < r1; rg += 4) {
         Aligned12 t0[4], t1[4];
-        Unaligned8 s0[4], s1[4];
         YTab2 y[4];
         int rr[4];
+        bool fresh[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             rr[k] = min(rg + k, rlast);
             y[k] = yt[rr[k]];
-            t0[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off0);
+            fresh[k] = y[k].off0 != (k == 0 ? prev_off : y[k - 1].off1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (fresh[k]) t0[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off0);
             t1[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off1);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            s0[k].lo = __builtin_amdgcn_alignbyte(t0[k].b, t0[k].a, shx);
-            s0[k].hi = __builtin_amdgcn_alignbyte(t0[k].c, t0[k].b, shx);
-            s1[k].lo = __builtin_amdgcn_alignbyte(t1[k].b, t1[k].a, shx);
-            s1[k].hi = __builtin_amdgcn_alignbyte(t1[k].c, t1[k].b, shx);
-        }
+            uint32_t h0[4], h1[4];
+            Unaligned8 s1;
+            s1.lo = __builtin_amdgcn_alignbyte(t1[k].b, t1[k].a, shx);
+            s1.hi = __builtin_amdgcn_alignbyte(t1[k].c, t1[k].b, shx);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
+            for (int j = 0; j < 4; j++) h1[j] = hpair(s1, x.sel[j], x.a01[j]);
+            if (fresh[k]) {
+                Unaligned8 s0;
+                s0.lo = __builtin_amdgcn_alignbyte(t0[k].b, t0[k].a, shx);
+                s0.hi = __builtin_amdgcn_alignbyte(t0[k].c, t0[k].b, shx);
+#pragma unroll
+                for (int j = 0; j < 4; j++) h0[j] = hpair(s0, x.sel[j], x.a01[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) h0[j] = hp[j];
+            }
             const uint32_t b0 = (uint32_t)y[k].b0, b1 = (uint32_t)y[k].b1;
             uint32_t o = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t h0 = hpair(s0[k], x.sel[j], x.a01[j]);
-                const uint32_t h1 = hpair(s1[k], x.sel[j], x.a01[j]);
-                const uint32_t v = (((b0 * h0) >> 16) + ((b1 * h1) >> 16) + 2u) >> 2;
+                const uint32_t v = (((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2u) >> 2;
                 o |= (v & 0xffu) << (8 * j);
+                hp[j] = h1[j];
             }
             *reinterpret_cast<uint32_t*>(dst + (size_t)rr[k] * L.pitch) = o;
         }
+        prev_off = y[3].off1;
     }
 }
 

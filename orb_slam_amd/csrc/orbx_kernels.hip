@@ -1439,7 +1439,7 @@ void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab
                          int nframes, hipStream_t s)
 {
     const LevelGeom& L = g.lv[level];
-    const int rows_per_band = 16;
+    const int rows_per_band = 8;     // measured: 8 beats 4, 16 and 32 (short wavefronts hide the load latency, long ones reuse more rows)
     const int ncb = (L.pitch / 4 + 63) / 64;
     const int nrb = (L.rows + rows_per_band - 1) / rows_per_band;
     dim3 grid((ncb * nrb + 3) / 4, nframes);

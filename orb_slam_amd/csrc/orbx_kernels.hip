@@ -615,6 +615,24 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     const uint32_t rcp_cw = fc.rcp_cw;                           // i / cw for i < 2^12, cw <= 64
     const int t = g.minTh;
     int nq = 0;
+    // The queue holds qcap entries, enough for any natural image; when a round might not fit
+    // (noise: most pixels pass), the queued pixels are scored at once and the queue restarts.
+    // `flushed` then sends the maxima search over all pixels instead of over the queue.
+    const int qcap = fl.queue_cap;
+    bool flushed = false;
+    auto score_queue = [&]() {
+        WAVE_SYNC();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < nq) {
+                const int i = s_queue[q];
+                const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
+                const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
+                s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
+            }
+        }
+        WAVE_SYNC();
+    };
     const int TP3 = 3 * TP;
     if (fc.rpr) {
         // whole rows per round: lane = (row r of the round, column c); a round advances every lane
@@ -625,6 +643,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         int addr = __mul24(r + 3, TP) + c + 3 + ox;
         int idx = r < R ? lane : npix;               // pixel index row * cw + c; idle lanes never pass the bound
         for (int y0 = 0; y0 < ch; y0 += R) {
+            if (nq + 64 > qcap) { score_queue(); nq = 0; flushed = true; }
             bool pass = false;
             if (idx < npix) {
                 const uint8_t* p = tile8 + addr;
@@ -653,6 +672,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             addr = __mul24(py0 + 3, TP) + px + 3 + ox;
         }
         for (int i0 = 0; i0 < npix; i0 += 64) {
+            if (nq + 64 > qcap) { score_queue(); nq = 0; flushed = true; }
             const int i = i0 + lane;
             bool pass = false;
             if (i < npix) {
@@ -673,23 +693,42 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             nq += __popcll(bal);
         }
     }
-    WAVE_SYNC();
-    for (int q0 = 0; q0 < nq; q0 += 64) {
-        const int q = q0 + lane;
-        if (q < nq) {
-            const int i = s_queue[q];
-            const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
-            const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
-            s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
-        }
-    }
-    WAVE_SYNC();
+    score_queue();
     // Strict 8-neighbour maxima.  Maxima that reach the initial threshold are emitted right
     // here, in queue (= row-major) order: if the cell has any, they are its whole result
     // (the first cv::FAST call of the reference found something).  Only a cell without one
     // needs the second sweep, which emits every flagged maximum (the minThFAST call).
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
     int base = 0;
+    if (flushed) {
+        // rare path: the queue no longer lists every candidate, so visit every pixel (row-major);
+        // first for maxima at the initial threshold, then, if there is none, for all maxima
+        for (int sweep = 0; sweep < 2 && base == 0; sweep++) {
+            for (int i0 = 0; i0 < npix; i0 += 64) {
+                const int i = i0 + lane;
+                bool hit = false;
+                int py = 0, px = 0, s = 0;
+                if (i < npix) {
+                    py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
+                    px = i - __mul24(py, cw);
+                    const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
+                    s = sc[0];
+                    const int m0 = max(max((int)sc[-SP - 1], (int)sc[-SP]), (int)sc[-SP + 1]);
+                    const int m1 = max(max((int)sc[SP - 1], (int)sc[SP]), (int)sc[SP + 1]);
+                    const int m2 = max(max((int)sc[-1], (int)sc[1]), 0);
+                    hit = s > max(max(m0, m1), m2) && (sweep == 1 || s >= g.iniTh);
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (pos < cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+                }
+                base += __popcll(bal);
+            }
+        }
+        if (lane == 0) *count_out = min(base, cell_cap);
+        return;
+    }
     for (int q0 = 0; q0 < nq; q0 += 64) {
         const int q = q0 + lane;
         bool hit = false;
@@ -1183,7 +1222,10 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     const int score_bytes = fl.score_pitch * (hc + 2);
     fl.score_off = (tile_bytes + 15) & ~15;
     fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
-    fl.total = fl.queue_off + 2 * wc * hc + 16;
+    // a queue for 640 pretest survivors (natural images: about 200 of a cell's ~1000 pixels) instead of one
+    // for every pixel keeps a wavefront's LDS under 5 KB, i.e. 8 wavefronts per SIMD
+    fl.queue_cap = std::min((wc * hc + 63) & ~63, getenv("ORBX_FAST_QCAP") ? atoi(getenv("ORBX_FAST_QCAP")) : 640);
+    fl.total = fl.queue_off + 2 * fl.queue_cap + 16;
     fl.total = (fl.total + 15) & ~15;
 }
 

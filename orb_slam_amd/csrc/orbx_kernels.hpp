@@ -24,6 +24,7 @@ struct SlideMap {
 struct FastLds {
     int tile_pitch, score_pitch;   // bytes per row of the pixel tile / score tile
     int score_off, queue_off;      // byte offsets inside the dynamic LDS block
+    int queue_cap;                 // entries of the pretest queue (multiple of 64)
     int total;                     // bytes of dynamic LDS per workgroup
     int fixed_pitch;               // 1: the pitches are the compile-time ones of the specialised kernel
 };

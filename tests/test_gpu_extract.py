@@ -115,6 +115,21 @@ def test_other_geometries(size, nfeat):
     ex.close()
 
 
+def test_fast_queue_overflow_path(oracle, monkeypatch):
+    """The per-cell FAST kernel queues pretest survivors in a bounded LDS queue and falls back to
+    a dense maxima search when a cell overflows it (noise).  Force the fallback everywhere with a
+    64-entry queue and require identical results, stage by stage."""
+    from orb_slam_amd import ORBextractor
+    monkeypatch.setenv("ORBX_FAST_QCAP", "64")
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    for img in (synthetic_frame(752, 480, 4242),
+                np.random.default_rng(6).integers(0, 256, size=(480, 752), dtype=np.uint8)):
+        kps_g, desc_g = ex(img)
+        kps_o, desc_o = _compare_frame(ex, oracle, img)
+        _assert_features(kps_g, desc_g, kps_o, desc_o)
+    ex.close()
+
+
 def test_strided_input(gpu, oracle):
     big = synthetic_frame(800, 480, 31)
     view = big[:, 24:24 + 752]           # stride 800, width 752

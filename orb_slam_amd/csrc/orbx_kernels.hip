@@ -786,14 +786,17 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
 // ---------------------------------------------------------------------------
 // block-wide scans (blockDim.x == 256)
 // ---------------------------------------------------------------------------
+// inclusive scan over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside each row of
+// 16 lanes (row_shr 1, 2, 4, 8 shifting zeros in), then the last lane of rows 0 and 2 is added to
+// rows 1 and 3 (row_bcast15), then lane 31 to rows 2 and 3 (row_bcast31)
 __device__ __forceinline__ int wave_incl_scan(int v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2, 3
     return v;
 }
 

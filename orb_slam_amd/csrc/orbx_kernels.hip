@@ -863,8 +863,9 @@ constexpr int kKeyRegs = 16;   // keys per thread held in registers (16 * 256 = 
 
 __device__ __forceinline__ int ceil_half(int d)
 {
-    // ceil(static_cast<float>(d) / 2) for integer d (src/ORBextractor.cc:433-434)
-    return (int)ceilf(__fdiv_rn((float)d, 2.0f));
+    // ceil(static_cast<float>(d) / 2) for integer d (src/ORBextractor.cc:433-434); node extents are
+    // non-negative and far below 2^24, where the float expression equals (d + 1) >> 1 exactly
+    return (d + 1) >> 1;
 }
 
 __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t* __restrict__ cell_cand,
@@ -1104,16 +1105,17 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             for (int s = tid; s < norder; s += 256) s_fl[s_order[s]] = 1;
             __syncthreads();
         }
-        // d. positions: children per parent (s_A), expandable children per parent (s_B), untouched nodes (s_C)
+        // d. positions: children per parent (s_A low half), expandable children per parent (s_A high half), untouched nodes (s_C)
         for (int s = tid; s < norder; s += 256) {
             int p = s_order[s];
-            s_A[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
-            s_B[s] = (s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1);
+            // both counts in one word (each sum stays below 2^16: at most 4 * 2048), one scan for the two
+            s_A[s] = ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) |
+                     (((s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1)) << 16);
         }
         for (int p = tid; p < size; p += 256) s_C[p] = !s_fl[p];
         __syncthreads();
-        const int totalch = lds_excl_scan(s_A, norder, s_tmp);
-        const int ncreated = lds_excl_scan(s_B, norder, s_tmp);
+        const int both = lds_excl_scan(s_A, norder, s_tmp);
+        const int totalch = both & 0xffff, ncreated = both >> 16;
         const int nold = lds_excl_scan(s_C, size, s_tmp);
         const int newsize = totalch + nold;
         // e. build the next list
@@ -1122,7 +1124,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             QNode q = rc[p];
             int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
             int nch = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
-            int pos = totalch - (s_A[s] + nch);   // children of later parents come first
+            int pos = totalch - ((s_A[s] & 0xffff) + nch);   // children of later parents come first
 #pragma unroll
             for (int qd = 3; qd >= 0; qd--)
                 if (s_cc[4 * p + qd] > 0) {
@@ -1137,7 +1139,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                     s_childpos[4 * p + qd] = (unsigned short)pos;
                     pos++;
                 }
-            int cb = s_B[s];
+            int cb = s_A[s] >> 16;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
                 if (s_cc[4 * p + qd] > 1) ci_nxt[s_childpos[4 * p + qd]] = (short)(cb++);

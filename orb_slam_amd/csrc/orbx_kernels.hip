@@ -859,7 +859,7 @@ __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
     const size_t M = (size_t)M_;
     return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
 }
-constexpr int kKeyRegs = 16;   // keys per thread held in registers (16 * 256 = 4096 keys per level)
+constexpr int kKeyRegs = 12;   // keys per thread held in registers (12 * 256 = 3072 keys per level; more than that would spill in the 128-VGPR build)
 
 __device__ __forceinline__ int ceil_half(int d)
 {
@@ -1187,11 +1187,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
 }
 
-#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds
-// Two builds of the same body.  k_quadtree keeps every key of a thread in registers (about 210
-// VGPRs, 2 wavefronts per SIMD): lowest latency, used for small batches.  k_quadtree_dense is
-// held to 128 VGPRs (4 wavefronts per SIMD, a few spills): more workgroups in flight, better
-// throughput once a batch has more workgroups than the device holds at once.
+// 108 VGPRs with 12 register keys per thread: 4 wavefronts per SIMD, nothing spilled (16 keys per
+// thread needed 210 VGPRs, and holding that build to 128 spilled 400 bytes per thread)
 __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
@@ -1199,19 +1196,9 @@ __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* _
                                                   int* __restrict__ level_count, int* __restrict__ level_ncand,
                                                   int off_in_lds)
 {
-    quadtree_body(QUADTREE_ARGS);
+    quadtree_body(g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand,
+                  off_in_lds);
 }
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_quadtree_dense(FrameGeom g, const uint32_t* __restrict__ cell_cand,
-                      const int* __restrict__ cell_count, int* __restrict__ cell_off,
-                      uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
-                      uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
-                      int* __restrict__ level_count, int* __restrict__ level_ncand, int off_in_lds)
-{
-    quadtree_body(QUADTREE_ARGS);
-}
-#undef QUADTREE_ARGS
 
 void make_fast_lds(const FrameGeom& g, FastLds& fl)
 {
@@ -1573,13 +1560,8 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
-    // 2 workgroups per CU fit with the register-resident build: beyond that the dense build wins
-    if (nframes * g.nlevels > 2 * 256)
-        hipLaunchKernelGGL(k_quadtree_dense, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy,
-                           key_resp, key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
-    else
-        hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
 }
 
 int quadtree_prepare(int max_nodes)
@@ -1589,9 +1571,6 @@ int quadtree_prepare(int max_nodes)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_dense),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     return 0;

@@ -642,22 +642,33 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         const int step_addr = R * TP, step_idx = R * cw;
         int addr = __mul24(r + 3, TP) + c + 3 + ox;
         int idx = r < R ? lane : npix;               // pixel index row * cw + c; idle lanes never pass the bound
-        for (int y0 = 0; y0 < ch; y0 += R) {
-            if (nq + 64 > qcap) { score_queue(); nq = 0; flushed = true; }
-            bool pass = false;
-            if (idx < npix) {
+        // two rounds per iteration: their ten LDS reads are in flight together and the loop
+        // bookkeeping is paid once
+        for (int y0 = 0; y0 < ch; y0 += 2 * R) {
+            if (nq + 128 > qcap) { score_queue(); nq = 0; flushed = true; }
+            const int idx2 = idx + step_idx;
+            bool pass = false, pass2 = false;
+            {
                 const uint8_t* p = tile8 + addr;
-                const int v = p[0];
-                const int p0 = p[TP3], p4 = p[3], p8 = p[-TP3], p12 = p[-3];
+                const uint8_t* p2 = p + step_addr;
+                // rows past the cell still lie inside the LDS block (the score tile follows): read, then discard
+                const int v = p[0], p0 = p[TP3], p4 = p[3], p8 = p[-TP3], p12 = p[-3];
+                const int w = p2[0], q0 = p2[TP3], q4 = p2[3], q8 = p2[-TP3], q12 = p2[-3];
                 const int br = min(max(p0, p8), max(p4, p12)) - v;
                 const int dk = v - max(min(p0, p8), min(p4, p12));
-                pass = max(br, dk) > t;
+                const int br2 = min(max(q0, q8), max(q4, q12)) - w;
+                const int dk2 = w - max(min(q0, q8), min(q4, q12));
+                pass = max(br, dk) > t && idx < npix;
+                pass2 = max(br2, dk2) > t && idx2 < npix;
             }
-            const unsigned long long bal = __ballot(pass);
-            if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)idx;
+            const unsigned long long below = (1ull << lane) - 1ull;
+            const unsigned long long bal = __ballot(pass), bal2 = __ballot(pass2);
+            if (pass) s_queue[nq + __popcll(bal & below)] = (uint16_t)idx;
             nq += __popcll(bal);
-            addr += step_addr;
-            idx += step_idx;
+            if (pass2) s_queue[nq + __popcll(bal2 & below)] = (uint16_t)idx2;
+            nq += __popcll(bal2);
+            addr += 2 * step_addr;
+            idx += 2 * step_idx;
         }
     } else {
         // the lane's pixel advances by 64 positions per round: keep its column and tile offset

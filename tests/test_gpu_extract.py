@@ -130,6 +130,21 @@ def test_fast_queue_overflow_path(oracle, monkeypatch):
     ex.close()
 
 
+@pytest.mark.parametrize("cfg", [(1500, 1.5, 5, 25, 10), (800, 1.1, 8, 12, 5), (300, 2.0, 3, 20, 7), (1000, 1.2, 1, 20, 7)])
+def test_other_extractor_settings(cfg, euroc_left):
+    """The constructor parameters of the reference's settings files vary (ORBextractor.nFeatures,
+    scaleFactor, nLevels, iniThFAST, minThFAST): every stage must follow the oracle for them too."""
+    from orb_slam_amd import ORBextractor
+    ex = ORBextractor(*cfg)
+    orc = Oracle(*cfg)
+    for img in (euroc_left, synthetic_frame(640, 480, 808)):
+        kps_g, desc_g = ex(img)
+        kps_o, desc_o = _compare_frame(ex, orc, img)
+        _assert_features(kps_g, desc_g, kps_o, desc_o)
+        assert np.array_equal(desc_g, desc_o)
+    ex.close()
+
+
 def test_strided_input(gpu, oracle):
     big = synthetic_frame(800, 480, 31)
     view = big[:, 24:24 + 752]           # stride 800, width 752

@@ -61,7 +61,6 @@ struct orbx_ctx {
     // geometry of the current frame size
     int gw = 0, gh = 0;
     FrameGeom g;
-    TileMap tm;
     SlideMap blur_map;
     FastLds fast_lds;
     DevBuf xtab, ytab, xtab4, ytab2, fast_cells;
@@ -153,7 +152,6 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
         HIPCHECK(c, hipMemcpyAsync(c->fast_cells.p, rt.fast_cells.data(), rt.fast_cells.size() * sizeof(FastCell), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));   // the tables are stack-owned
     c->g = g;
-    make_blur_tilemap(c->g, c->tm);
     // short bands: the kernel is bound by the latency of its dependent row groups, and many short
     // wavefronts hide it better than few long ones (measured optimum 12 rows, 6 of warm-up included)
     make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 12, c->blur_map);
@@ -230,8 +228,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         return ORBX_OK;
     }
     t0(ST_FAST, s);
-    if (getenv("ORBX_OLD_FAST")) launch_fast_cells(c->pyr.as<uint8_t>(), g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
-    else launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->fast_cells.as<FastCell>(), c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->fast_cells.as<FastCell>(), c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
     t1(ST_FAST, s);
     // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
     // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
@@ -242,8 +239,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipStreamWaitEvent(bs, c->ev_pyr, 0));
     }
     t0(ST_BLUR, bs);
-    if (getenv("ORBX_OLD_BLUR")) launch_blur(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->tm, nframes, bs);
-    else launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, bs);
+    launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, bs);
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);

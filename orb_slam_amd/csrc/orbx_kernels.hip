@@ -1,12 +1,13 @@
 // orbx_kernels.hip -- gfx950 kernels of the ORB extraction path.
 //
 // Stage order of one batch (every kernel covers all frames of the batch):
-//   k_pyr_level0   copyMakeBorder of the input into level 0        (src/ORBextractor.cc:1212-1213)
-//   k_pyr_resize   level l from level l-1 + REFLECT_101 border     (:1205-1208)
-//   k_blur         7x7 Gaussian of every level                     (:1169-1170)
-//   k_fast_cells   per-cell FAST-9/16 + NMS + threshold fallback   (:1052-1101)
-//   k_quadtree     DistributeOctTree                               (:488-711)
-//   k_orient_desc  IC_Angle + rBRIEF + output assembly             (:74-150, :1109-1124, :1173-1188)
+//   k_pyr_level0       copyMakeBorder of the input into level 0        (src/ORBextractor.cc:1212-1213)
+//   k_resize_slide     level l from level l-1 + REFLECT_101 border     (:1205-1208)
+//                      (k_pyr_resize: same result, for scale factors whose 4-pixel source window exceeds 8 bytes)
+//   k_fast_cells_wave  per-cell FAST-9/16 + NMS + threshold fallback   (:1052-1101)
+//   k_blur_slide       7x7 Gaussian of every level                     (:1169-1170)
+//   k_quadtree         DistributeOctTree                               (:488-711)
+//   k_orient_desc      IC_Angle + rBRIEF + output assembly             (:74-150, :1109-1124, :1173-1188)
 //
 // All arithmetic that decides a result is integer, or float written with
 // explicit round-to-nearest intrinsics (no contraction), so that results are
@@ -236,63 +237,8 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
 // ---------------------------------------------------------------------------
 // 7x7 Gaussian blur, sigma 2, 8.8 fixed-point taps, exact integer sums,
 // dst = min(255, (acc + 32768) >> 16).  Reads the REFLECT_101 border that is
-// stored in the plane.  One workgroup = one 64 x 32 output tile.
-// ---------------------------------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 32;
-
-__global__ __launch_bounds__(256) void k_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                              FrameGeom g, TileMap tm)
-{
-    __shared__ uint32_t s_in[(kBlurTH + 6) * 18];            // 38 rows x 72 bytes
-    __shared__ uint16_t s_h[(kBlurTH + 6) * kBlurTW];        // horizontal sums
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < kMaxLevels; l++)
-        if (l < g.nlevels && (int)blockIdx.x >= tm.base[l]) level = l;
-    const LevelGeom& L = g.lv[level];
-    const int t = blockIdx.x - tm.base[level];
-    const int tx = t % tm.tiles_x[level], ty = t / tm.tiles_x[level];
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
-    const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
-    const uint8_t* plane = pyr + fbase;
-    const int tid = threadIdx.x;
-
-    // input tile: plane rows kPadY+y0-3 .. +38, plane cols kPadX+x0-4 .. +72 (dword aligned)
-    for (int i = tid; i < (kBlurTH + 6) * 18; i += 256) {
-        int r = i / 18, c = i - r * 18;
-        int prow = kPadY + y0 - 3 + r;
-        int pcol = kPadX + x0 - 4 + 4 * c;
-        uint32_t v = 0;
-        if (prow < L.rows && pcol + 4 <= L.pitch)
-            v = *reinterpret_cast<const uint32_t*>(plane + (size_t)prow * L.pitch + pcol);
-        s_in[i] = v;
-    }
-    __syncthreads();
-    const uint8_t* in8 = reinterpret_cast<const uint8_t*>(s_in);
-    const int k0 = c_gauss[0], k1 = c_gauss[1], k2 = c_gauss[2], k3 = c_gauss[3];
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        int r = i >> 6, c = i & 63;
-        const uint8_t* p = in8 + r * 72 + c + 1;   // pixel x0+c-3
-        int acc = k0 * (p[0] + p[6]) + k1 * (p[1] + p[5]) + k2 * (p[2] + p[4]) + k3 * p[3];
-        s_h[i] = (uint16_t)acc;                    // <= 255*257 = 65535
-    }
-    __syncthreads();
-    const int c = tid & 63, rg = tid >> 6;          // 4 row groups of 8 rows
-    uint8_t* out = blur + fbase;
-    for (int j = 0; j < 8; j++) {
-        int r = rg * 8 + j;
-        const uint16_t* h = s_h + r * kBlurTW + c;
-        int acc = k0 * (h[0] + h[6 * kBlurTW]) + k1 * (h[kBlurTW] + h[5 * kBlurTW]) +
-                  k2 * (h[2 * kBlurTW] + h[4 * kBlurTW]) + k3 * h[3 * kBlurTW];
-        int v = (acc + 32768) >> 16;
-        v = v > 255 ? 255 : v;
-        int x = x0 + c, y = y0 + r;
-        if (x < L.w && y < L.h) out[(size_t)(kPadY + y) * L.pitch + kPadX + x] = (uint8_t)v;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Sliding-window form of the same blur: a lane owns 4 adjacent pixels (one
+// stored in the plane.
+// Sliding-window form: a lane owns 4 adjacent pixels (one
 // dword) of a column block and walks down a band of rows, keeping the last 7
 // horizontal sums of its pixels in registers.  No LDS, no barriers: one
 // 12-byte load, 14 byte-alignment / dot4 operations for the 4 horizontal sums,
@@ -436,118 +382,7 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int pitch)
     return max(v - mnmx, mxmn - v) - 1;
 }
 
-constexpr int kCellMax = 64;                       // largest cell side supported
 constexpr int kFastTileFixed = 48, kFastScoreFixed = 40;   // pitches of the specialised wave-per-cell kernel
-constexpr int kTilePitch = kCellMax + 6 + 6;       // LDS row pitch of the pixel tile (bytes, multiple of 4)
-constexpr int kScorePitch = kCellMax + 4;          // LDS row pitch of the score tile
-
-// One workgroup per (cell, frame).  The cells' tested areas tile
-// [3,width-3) x [3,height-3) of the detection region; a non-maximum test sees
-// score 0 outside its own cell's area (each cell is a separate cv::FAST call in
-// the reference).  Output: the cell's keypoints in row-major order, packed
-// (y_local << 16 | x_local << 8 | score), and their count.
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, FrameGeom g,
-                                                    uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count)
-{
-    __shared__ uint32_t s_tile[(kCellMax + 6) * (kTilePitch / 4)];
-    __shared__ uint8_t s_score[(kCellMax + 2) * kScorePitch];
-    __shared__ int s_wcount[4];
-    __shared__ int s_any_ini;
-
-    const int tid = threadIdx.x;
-    const int cell = blockIdx.x, f = blockIdx.y;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < kMaxLevels; l++)
-        if (l < g.nlevels && g.lv[l].width > 0 && cell >= g.lv[l].cell_base) level = l;
-    const LevelGeom& L = g.lv[level];
-    const int cl = cell - L.cell_base;
-    const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
-    // tested area of this cell, relative to the detection origin (16,16)
-    const int tx0 = cj * L.wCell + 3, tx1 = min((cj + 1) * L.wCell + 3, L.width - 3);
-    const int ty0 = ci * L.hCell + 3, ty1 = min((ci + 1) * L.hCell + 3, L.height - 3);
-    const int cw = tx1 - tx0, ch = ty1 - ty0;
-    int* count_out = cell_count + (size_t)f * g.ncells + cell;
-    if (cw <= 0 || ch <= 0) {
-        if (tid == 0) *count_out = 0;
-        return;
-    }
-    // pixel tile with the 3-pixel ring margin, fetched as aligned dwords
-    const uint8_t* plane = pyr + (size_t)f * g.pyr_frame_bytes + L.plane_off;
-    const int pcol0 = kPadX + kDetBorder + tx0 - 3;       // plane column of tile column 0
-    const int prow0 = kPadY + kDetBorder + ty0 - 3;
-    const int acol0 = pcol0 & ~3, ox = pcol0 - acol0;
-    const int ndw = (ox + cw + 6 + 3) >> 2;
-    const int th = ch + 6;
-    for (int i = tid; i < th * ndw; i += 256) {
-        int r = i / ndw, c = i - r * ndw;
-        s_tile[r * (kTilePitch / 4) + c] =
-            *reinterpret_cast<const uint32_t*>(plane + (size_t)(prow0 + r) * L.pitch + acol0 + 4 * c);
-    }
-    // score tile with a zero ring
-    for (int i = tid; i < (ch + 2) * kScorePitch; i += 256) s_score[i] = 0;
-    if (tid == 0) s_any_ini = 0;
-    __syncthreads();
-
-    const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
-    const int npix = cw * ch;
-    for (int i = tid; i < npix; i += 256) {
-        int py = i / cw, px = i - py * cw;
-        int s = fast_score_lds(tile8 + (py + 3) * kTilePitch + px + 3 + ox, kTilePitch);
-        s_score[(py + 1) * kScorePitch + px + 1] = (uint8_t)((s >= g.minTh && s > 0) ? s : 0);
-    }
-    __syncthreads();
-
-    // strict 8-neighbour maxima; does the cell own one with score >= iniTh ?
-    uint32_t is_max = 0;   // bit k: pixel tid + 256*k
-    int any_ini = 0;
-    for (int i = tid, k = 0; i < npix; i += 256, k++) {
-        int py = i / cw, px = i - py * cw;
-        const uint8_t* sc = s_score + (py + 1) * kScorePitch + px + 1;
-        int s = sc[0];
-        if (s > 0 && s > sc[-1] && s > sc[1] &&
-            s > sc[-kScorePitch - 1] && s > sc[-kScorePitch] && s > sc[-kScorePitch + 1] &&
-            s > sc[kScorePitch - 1] && s > sc[kScorePitch] && s > sc[kScorePitch + 1]) {
-            is_max |= 1u << k;
-            any_ini |= (s >= g.iniTh);
-        }
-    }
-    if (any_ini) s_any_ini = 1;
-    __syncthreads();
-    const int use_ini = s_any_ini;
-
-    // ordered compaction (row-major inside the cell)
-    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + (size_t)cl * L.cell_cap;
-    const int lane = tid & 63, wave = tid >> 6;
-    int base = 0;
-    for (int i0 = 0, k = 0; i0 < npix; i0 += 256, k++) {
-        int i = i0 + tid;
-        int py = 0, px = 0, s = 0, keep = 0;
-        if (i < npix && ((is_max >> k) & 1)) {
-            py = i / cw;
-            px = i - py * cw;
-            s = s_score[(py + 1) * kScorePitch + px + 1];
-            keep = !use_ini || s >= g.iniTh;
-        }
-        unsigned long long bal = __ballot(keep);
-        __syncthreads();
-        if (lane == 0) s_wcount[wave] = __popcll(bal);
-        __syncthreads();
-        int before = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 4; w++) {
-            int c = s_wcount[w];
-            if (w < wave) before += c;
-            total += c;
-        }
-        if (keep) {
-            int pos = base + before + __popcll(bal & ((1ull << lane) - 1ull));
-            if (pos < L.cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
-        }
-        base += total;
-    }
-    if (tid == 0) *count_out = min(base, L.cell_cap);
-}
 
 // ---------------------------------------------------------------------------
 // Per-cell FAST, one wavefront per cell.  Most pixels fail a 4-point necessary
@@ -556,7 +391,10 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
 // same side); the survivors are queued in pixel order and only they get the
 // full score.  Everything after the tile load is wave-synchronous: ballots and
 // lane prefix counts keep the queue, and therefore the output, in row-major
-// order.  Results are identical to k_fast_cells.
+// order.  The cells' tested areas tile [3,width-3) x [3,height-3) of the detection region; a
+// non-maximum test sees score 0 outside its own cell's area (each cell is a separate cv::FAST
+// call in the reference).  Output: the cell's keypoints in row-major order, packed
+// (y_local << 16 | x_local << 8 | score), and their count.
 // ---------------------------------------------------------------------------
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // TPC / SPC: compile-time tile and score pitches (0 = take them from fl): with constants every
@@ -1491,26 +1329,6 @@ void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab
     hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb);
 }
 
-void make_blur_tilemap(const FrameGeom& g, TileMap& tm)
-{
-    int base = 0;
-    for (int l = 0; l < kMaxLevels; l++) {
-        tm.base[l] = base;
-        tm.tiles_x[l] = 1;
-        if (l < g.nlevels) {
-            tm.tiles_x[l] = (g.lv[l].w + kBlurTW - 1) / kBlurTW;
-            base += tm.tiles_x[l] * ((g.lv[l].h + kBlurTH - 1) / kBlurTH);
-        }
-    }
-    tm.base[kMaxLevels] = base;
-}
-
-void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const TileMap& tm, int nframes, hipStream_t s)
-{
-    dim3 grid(tm.base[kMaxLevels], nframes);
-    hipLaunchKernelGGL(k_blur, grid, dim3(256), 0, s, pyr, blur, g, tm);
-}
-
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
 {
     int base = 0;
@@ -1538,14 +1356,6 @@ void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, co
 {
     dim3 grid((sm.base[kMaxLevels] + 3) / 4, nframes);
     hipLaunchKernelGGL(k_blur_slide, grid, dim3(256), 0, s, pyr, blur, g, sm);
-}
-
-void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
-                       int nframes, hipStream_t s)
-{
-    if (g.ncells == 0) return;
-    dim3 grid(g.ncells, nframes);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, s, pyr, g, cell_cand, cell_count);
 }
 
 static int max_level_cells(const FrameGeom& g)

@@ -6,11 +6,6 @@
 
 namespace orbx {
 
-struct TileMap {
-    int base[kMaxLevels + 1];   // first tile of each level; [kMaxLevels] = total
-    int tiles_x[kMaxLevels];
-};
-
 // work items of the sliding-window kernels: (level, 64-dword column block, row band)
 struct SlideMap {
     int base[kMaxLevels + 1];   // first item of each level; [kMaxLevels] = total
@@ -39,13 +34,9 @@ void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* 
                        int nframes, hipStream_t s);
 void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
                          int nframes, hipStream_t s);
-void make_blur_tilemap(const FrameGeom& g, TileMap& tm);
-void launch_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const TileMap& tm, int nframes, hipStream_t s);
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm);
 void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
                        hipStream_t s);
-void launch_fast_cells(const uint8_t* pyr, const FrameGeom& g, uint32_t* cell_cand, int* cell_count,
-                       int nframes, hipStream_t s);
 void make_fast_lds(const FrameGeom& g, FastLds& fl);
 void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, const FastCell* cells, uint32_t* cell_cand,
                             int* cell_count, int nframes, hipStream_t s);

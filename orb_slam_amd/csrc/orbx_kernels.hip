@@ -708,7 +708,7 @@ __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
     const size_t M = (size_t)M_;
     return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
 }
-constexpr int kKeyRegs = 12;   // keys per thread held in registers (12 * 256 = 3072 keys per level; more than that would spill in the 128-VGPR build)
+constexpr int kKeyRegs = 10;   // keys per thread held in registers (10 * 256 = 2560 keys per level); 91 VGPRs = 5 wavefronts per SIMD. 16 keys cost 210 VGPRs (2 per SIMD) and 40 % of the time
 
 __device__ __forceinline__ int ceil_half(int d)
 {
@@ -1036,8 +1036,6 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
 }
 
-// 108 VGPRs with 12 register keys per thread: 4 wavefronts per SIMD, nothing spilled (16 keys per
-// thread needed 210 VGPRs, and holding that build to 128 spilled 400 bytes per thread)
 __global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,

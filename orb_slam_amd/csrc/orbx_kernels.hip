@@ -1185,21 +1185,23 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
         bx = blockIdx.x;
         f = blockIdx.y;
     }
-    const int slot = bx * 8 + (tid >> 5);
+    // every level owns whole groups of 8 slots, so the level of this workgroup's 8 keypoints is
+    // uniform: the search runs on the scalar unit
+    const int slot0 = bx * 8;
     const int* lc = level_count + f * kMaxLevels;
-    int level = -1, k = 0, prefix = 0, total = 0;
+    int level = -1, prefix = 0, total = 0;
 #pragma unroll
     for (int l = 0; l < kMaxLevels; l++) {
         if (l < g.nlevels) {
             const int c = lc[l];
-            if (g.lv[l].kp_cap > 0 && slot >= g.lv[l].kp_base && slot < g.lv[l].kp_base + g.lv[l].kp_cap) {
+            if (g.lv[l].kp_cap > 0 && slot0 >= g.lv[l].kp_base && slot0 < g.lv[l].kp_base + g.lv[l].kp_cap) {
                 level = l;
-                k = slot - g.lv[l].kp_base;
                 prefix = total;
             }
             total += c;
         }
     }
+    const int k = level >= 0 ? slot0 - g.lv[level].kp_base + (tid >> 5) : 0;
     if (bx == 0 && tid == 0) n_out[f] = total;
     if (level < 0 || k >= lc[level]) return;
     const int oi = prefix + k;

@@ -171,7 +171,7 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
             L.kp_cap = std::max(L.nfeat + 3, 4 * L.nIni);
             if (L.kp_cap + 4 > kMaxNodes) { *msg = "more than 2040 features on one level"; return ORBX_ERR_UNSUPPORTED; }
             max_nodes = std::max(max_nodes, L.kp_cap + 4);
-            kps += L.kp_cap;
+            kps += (L.kp_cap + 7) & ~7;    // whole groups of 8 slots per level: a descriptor workgroup (8 keypoints) never straddles levels
         }
         // A level whose search region is smaller than one 30-pixel cell yields no
         // keypoints (the reference would divide by zero there).

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
 #undef WAVE_SYNC
 
 // ---------------------------------------------------------------------------
-// block-wide scans (blockDim.x == 256)
+// block-wide scans (NT threads = NT / 64 wavefronts per workgroup)
 // ---------------------------------------------------------------------------
 // inclusive scan over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside each row of
 // 16 lanes (row_shr 1, 2, 4, 8 shifting zeros in), then the last lane of rows 0 and 2 is added to
@@ -649,7 +649,8 @@ __device__ __forceinline__ int wave_incl_scan(int v)
     return v;
 }
 
-// exclusive scan of one value per thread; tmp = 4 ints of LDS
+// exclusive scan of one value per thread; tmp = NT / 64 ints of LDS
+template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
 {
     const int incl = wave_incl_scan(v);
@@ -659,7 +660,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NT / 64; i++) {
         int t = tmp[i];
         if (i < w) base += t;
         tot += t;
@@ -669,14 +670,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
 }
 
 // in-place exclusive scan of an LDS array; returns the total to every thread
+template <int NT>
 __device__ __forceinline__ int lds_excl_scan(int* a, int n, int* tmp)
 {
-    const int chunk = (n + 255) >> 8;
+    const int chunk = (n + NT - 1) / NT;
     const int b = min((int)threadIdx.x * chunk, n), e = min(b + chunk, n);
     int s = 0;
     for (int i = b; i < e; i++) s += a[i];
     int tot;
-    int base = block_excl_scan(s, tmp, &tot);
+    int base = block_excl_scan<NT>(s, tmp, &tot);
     for (int i = b; i < e; i++) {
         int t = a[i];
         a[i] = base;
@@ -706,8 +708,9 @@ struct QNode { short x0, x1, y0, y1; };
 __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
 {
     const size_t M = (size_t)M_;
-    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 16 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
+    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 32 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
 }
+constexpr int kKeyRegsWide = 3;   // register keys per thread of the 1024-thread shape (3072 keys per level)
 constexpr int kKeyRegs = 10;   // keys per thread held in registers (10 * 256 = 2560 keys per level); 91 VGPRs = 5 wavefronts per SIMD. 16 keys cost 210 VGPRs (2 per SIMD) and 40 % of the time
 
 __device__ __forceinline__ int ceil_half(int d)
@@ -717,6 +720,7 @@ __device__ __forceinline__ int ceil_half(int d)
     return (d + 1) >> 1;
 }
 
+template <int NT, int KR>
 __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
@@ -742,14 +746,14 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     int* s_B = s_A + M;                                                                 // M
     int* s_C = s_B + M;                                                                 // M
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                                 // M (only while ranking)
-    int* s_var = s_C + M;                                                               // 16
-    short* s_cidx = reinterpret_cast<short*>(s_var + 16);                               // 2*M
+    int* s_var = s_C + M;                                                               // 32
+    short* s_cidx = reinterpret_cast<short*>(s_var + 32);                               // 2*M
     unsigned short* s_childpos = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);     // 4*M
     unsigned short* s_newpos = s_childpos + 4 * M;                                      // M
     unsigned short* s_order = s_newpos + M;                                             // M
     unsigned short* s_cand = s_order + M;                                               // M
     unsigned char* s_fl = reinterpret_cast<unsigned char*>(s_cand + M);                 // M
-    int* s_tmp = s_var;          // [0..3] scan scratch
+    int* s_tmp = s_var + 16;     // scan scratch, one int per wavefront
     // s_var[4]=size [5]=phase2 [6]=finish [7]=cntlt
 
     const int N = L.nfeat;
@@ -767,25 +771,25 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     int n;
     int* s_off = reinterpret_cast<int*>(smem + quadtree_fixed_lds(M));    // ncell + 1 entries, if off_in_lds
     {
-        const int chunk = (ncell + 255) >> 8;
+        const int chunk = (ncell + NT - 1) / NT;
         const int b = min(tid * chunk, ncell), e = min(b + chunk, ncell);
         int s = 0;
         for (int c = b; c < e; c++) s += ccount[c];
-        int base = block_excl_scan(s, s_tmp, &n);
+        int base = block_excl_scan<NT>(s, s_tmp, &n);
         for (int c = b; c < e; c++) {
             if (off_in_lds) s_off[c] = base; else coff[c] = base;
             base += ccount[c];
         }
-        if (tid == 255) { if (off_in_lds) s_off[ncell] = n; }
+        if (tid == NT - 1) { if (off_in_lds) s_off[ncell] = n; }
         __syncthreads();
     }
     if (tid == 0) level_ncand[f * kMaxLevels + level] = n;
 
-    // The first kKeyRegs*256 keys live in registers (coordinates, response and current node);
+    // The first KR*NT keys live in registers (coordinates, response and current node);
     // only the rare overflow beyond that walks the global arrays.  FOR_KEYS(body) runs body
     // for every key of this thread with `i` (key index), `xy` (packed coordinates) and `nd`
     // (node word: node | quadrant << 11 | response << 16, written back afterwards).
-    uint32_t rxy[kKeyRegs], rnode[kKeyRegs];
+    uint32_t rxy[KR], rnode[KR];
     auto fetch_key = [&](int i, uint32_t& xy, uint32_t& resp) {
         int lo = 0, hi = ncell;                 // largest c with off[c] <= i
         while (hi - lo > 1) {
@@ -805,8 +809,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         kresp[i] = (uint8_t)resp;
     };
 #pragma unroll
-    for (int k = 0; k < kKeyRegs; k++) {
-        const int i = tid + 256 * k;
+    for (int k = 0; k < KR; k++) {
+        const int i = tid + NT * k;
         rxy[k] = 0u;
         rnode[k] = 0u;
         if (i < n) {
@@ -815,15 +819,15 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             rnode[k] = resp << 16;
         }
     }
-    for (int i = tid + 256 * kKeyRegs; i < n; i += 256) {
+    for (int i = tid + NT * KR; i < n; i += NT) {
         uint32_t xy, resp;
         fetch_key(i, xy, resp);
         knode[i] = 0;
     }
     __syncthreads();
 #define FOR_KEYS(...)                                                           \
-    _Pragma("unroll") for (int k_ = 0; k_ < kKeyRegs; k_++) {                   \
-        const int i = tid + 256 * k_;                                           \
+    _Pragma("unroll") for (int k_ = 0; k_ < KR; k_++) {                   \
+        const int i = tid + NT * k_;                                           \
         if (i < n) {                                                            \
             const uint32_t xy = rxy[k_];                                        \
             uint32_t nd = rnode[k_] & 0xffffu;                                  \
@@ -833,7 +837,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             rnode[k_] = (nd & 0xffffu) | (resp << 16);                          \
         }                                                                       \
     }                                                                           \
-    for (int i = tid + 256 * kKeyRegs; i < n; i += 256) {                       \
+    for (int i = tid + NT * KR; i < n; i += NT) {                       \
         const uint32_t xy = kxy[i];                                             \
         uint32_t nd = knode[i];                                                 \
         const uint32_t resp = kresp[i];                                         \
@@ -845,7 +849,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     // ---- root nodes (:492-534)
     const int nIni = L.nIni;
     const float hX = L.hX;
-    for (int r = tid; r < nIni; r += 256) s_A[r] = 0;
+    for (int r = tid; r < nIni; r += NT) s_A[r] = 0;
     __syncthreads();
     FOR_KEYS({
         int x = (int)(xy & 0xffff);
@@ -855,11 +859,11 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         nd = (uint32_t)r;
     })
     __syncthreads();
-    for (int r = tid; r < nIni; r += 256) s_B[r] = s_A[r] > 0;
+    for (int r = tid; r < nIni; r += NT) s_B[r] = s_A[r] > 0;
     __syncthreads();
-    int size = lds_excl_scan(s_B, nIni, s_tmp);
+    int size = lds_excl_scan<NT>(s_B, nIni, s_tmp);
     int cur = 0;
-    for (int r = tid; r < nIni; r += 256)
+    for (int r = tid; r < nIni; r += NT)
         if (s_A[r] > 0) {
             int pos = s_B[r];
             QNode q;
@@ -888,7 +892,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         short* ci_nxt = s_cidx + (cur ^ 1) * M;
 
         // a. nodes that may be split in this step; clear child counts
-        for (int p = tid; p < size; p += 256) {
+        for (int p = tid; p < size; p += NT) {
             int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
             s_fl[p] = (unsigned char)e;
             s_A[p] = e;
@@ -910,14 +914,14 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         })
         __syncthreads();
         // c. processing order of the parents
-        int norder = lds_excl_scan(s_A, size, s_tmp);   // s_A[p] = index among flagged nodes, list order
+        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);   // s_A[p] = index among flagged nodes, list order
         if (!phase2) {
-            for (int p = tid; p < size; p += 256)
+            for (int p = tid; p < size; p += NT)
                 if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
             __syncthreads();
         } else {
             const int m = norder;
-            for (int p = tid; p < size; p += 256)
+            for (int p = tid; p < size; p += NT)
                 if (s_fl[p]) {
                     s_cand[s_A[p]] = (unsigned short)p;
                     s_key[s_A[p]] = (uint32_t)cc_cur[p];     // size
@@ -925,7 +929,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 }
             __syncthreads();
             // rank in (size, creation) descending order
-            for (int i = tid; i < m; i += 256) {
+            for (int i = tid; i < m; i += NT) {
                 const uint32_t ki = s_key[i];
                 const int ci = s_B[i];
                 int r = 0;
@@ -937,38 +941,38 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             }
             __syncthreads();
             // growth of |L| per split, in processing order; first index reaching N
-            for (int s = tid; s < m; s += 256) {
+            for (int s = tid; s < m; s += NT) {
                 int p = s_order[s];
                 s_B[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0) - 1;
                 s_C[s] = s_B[s];
             }
             __syncthreads();
-            lds_excl_scan(s_C, m, s_tmp);
+            lds_excl_scan<NT>(s_C, m, s_tmp);
             int below = 0;
-            for (int s = tid; s < m; s += 256) below += (size + s_C[s] + s_B[s] < N);
+            for (int s = tid; s < m; s += NT) below += (size + s_C[s] + s_B[s] < N);
             if (below) atomicAdd(&s_var[7], below);
             __syncthreads();
             norder = min(s_var[7] + 1, m);
-            for (int p = tid; p < size; p += 256) s_fl[p] = 0;
+            for (int p = tid; p < size; p += NT) s_fl[p] = 0;
             __syncthreads();
-            for (int s = tid; s < norder; s += 256) s_fl[s_order[s]] = 1;
+            for (int s = tid; s < norder; s += NT) s_fl[s_order[s]] = 1;
             __syncthreads();
         }
         // d. positions: children per parent (s_A low half), expandable children per parent (s_A high half), untouched nodes (s_C)
-        for (int s = tid; s < norder; s += 256) {
+        for (int s = tid; s < norder; s += NT) {
             int p = s_order[s];
             // both counts in one word (each sum stays below 2^16: at most 4 * 2048), one scan for the two
             s_A[s] = ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) |
                      (((s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1)) << 16);
         }
-        for (int p = tid; p < size; p += 256) s_C[p] = !s_fl[p];
+        for (int p = tid; p < size; p += NT) s_C[p] = !s_fl[p];
         __syncthreads();
-        const int both = lds_excl_scan(s_A, norder, s_tmp);
+        const int both = lds_excl_scan<NT>(s_A, norder, s_tmp);
         const int totalch = both & 0xffff, ncreated = both >> 16;
-        const int nold = lds_excl_scan(s_C, size, s_tmp);
+        const int nold = lds_excl_scan<NT>(s_C, size, s_tmp);
         const int newsize = totalch + nold;
         // e. build the next list
-        for (int s = tid; s < norder; s += 256) {
+        for (int s = tid; s < norder; s += NT) {
             int p = s_order[s];
             QNode q = rc[p];
             int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
@@ -993,7 +997,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             for (int qd = 0; qd < 4; qd++)
                 if (s_cc[4 * p + qd] > 1) ci_nxt[s_childpos[4 * p + qd]] = (short)(cb++);
         }
-        for (int p = tid; p < size; p += 256)
+        for (int p = tid; p < size; p += NT)
             if (!s_fl[p]) {
                 int pos = totalch + s_C[p];
                 s_newpos[p] = (unsigned short)pos;
@@ -1020,7 +1024,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 
     // ---- best key of every node (:689-710): largest response, first key on ties
     size = s_var[4];
-    for (int p = tid; p < size; p += 256) s_best[p] = 0ull;
+    for (int p = tid; p < size; p += NT) s_best[p] = 0ull;
     __syncthreads();
     FOR_KEYS({
         unsigned long long v = ((unsigned long long)resp << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
@@ -1029,23 +1033,25 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 #undef FOR_KEYS
     __syncthreads();
     uint2* stage = kp_stage + (size_t)f * g.kp_per_frame + L.kp_base;
-    for (int p = tid; p < size && p < L.kp_cap; p += 256) {
+    for (int p = tid; p < size && p < L.kp_cap; p += NT) {
         uint32_t i = 0xFFFFFFFFu - (uint32_t)(s_best[p] & 0xFFFFFFFFull);
         stage[p] = make_uint2(kxy[i], (uint32_t)(s_best[p] >> 32));
     }
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
 }
 
-__global__ __launch_bounds__(256) void k_quadtree(FrameGeom g, const uint32_t* __restrict__ cell_cand,
-                                                  const int* __restrict__ cell_count, int* __restrict__ cell_off,
-                                                  uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
-                                                  uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
-                                                  int* __restrict__ level_count, int* __restrict__ level_ncand,
-                                                  int off_in_lds)
-{
-    quadtree_body(g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand,
-                  off_in_lds);
-}
+#define QUADTREE_PARAMS FrameGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_count,          \
+                        int* __restrict__ cell_off, uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,      \
+                        uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage, int* __restrict__ level_count,   \
+                        int* __restrict__ level_ncand, int off_in_lds
+#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds
+// Two shapes of the same body.  256 threads x 10 register keys (91 VGPRs, 5 wavefronts per SIMD) is
+// the throughput shape for batches.  1024 threads x 3 register keys shortens the per-key passes of
+// a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
+__global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide>(QUADTREE_ARGS); }
+#undef QUADTREE_ARGS
+#undef QUADTREE_PARAMS
 
 void make_fast_lds(const FrameGeom& g, FastLds& fl)
 {
@@ -1381,8 +1387,15 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
-    hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                       key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    // up to one workgroup per CU (32 frames x 8 levels) the wide shape is faster, beyond that the narrow one (measured)
+    const char* e_wide = getenv("ORBX_QT_WIDE_MAX");
+    const int wide_max = e_wide ? atoi(e_wide) : 32;
+    if (nframes <= wide_max)
+        hipLaunchKernelGGL(k_quadtree_wide, grid, dim3(1024), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    else
+        hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
 }
 
 int quadtree_prepare(int max_nodes)
@@ -1392,6 +1405,9 @@ int quadtree_prepare(int max_nodes)
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_wide),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }
     return 0;

@@ -115,6 +115,18 @@ def test_other_geometries(size, nfeat):
     ex.close()
 
 
+def test_quadtree_batch_shape_on_small_batch(gpu, oracle, monkeypatch):
+    """Small batches run the quadtree on 1024-thread workgroups, large ones on 256-thread ones.
+    Force the large-batch shape on a small batch: same keypoints."""
+    monkeypatch.setenv("ORBX_QT_WIDE_MAX", "0")
+    imgs = synthetic_batch(2, 752, 480, seed0=4300)
+    res = gpu.extract_batch(imgs)
+    for i in range(2):
+        kps_o, desc_o = _compare_frame(gpu, oracle, imgs[i], frame=i)
+        _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+        assert np.array_equal(res[i][1], desc_o)
+
+
 def test_fast_queue_overflow_path(oracle, monkeypatch):
     """The per-cell FAST kernel queues pretest survivors in a bounded LDS queue and falls back to
     a dense maxima search when a cell overflows it (noise).  Force the fallback everywhere with a

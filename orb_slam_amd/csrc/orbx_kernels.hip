@@ -208,7 +208,8 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
             uint32_t o = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const uint32_t v = (((b0 * h0[j]) >> 16) + ((b1 * h1[j]) >> 16) + 2u) >> 2;
+                // 24-bit multiplies (weights <= 2048, sums < 2^15): full rate, a 32-bit v_mul_lo is not
+                const uint32_t v = ((__umul24(b0, h0[j]) >> 16) + (__umul24(b1, h1[j]) >> 16) + 2u) >> 2;
                 o |= (v & 0xffu) << (8 * j);
                 hp[j] = h1[j];
             }
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
             blur_hsum4w(raw[p][0], raw[p][1], raw[p][2], hc);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t s = 18u * hc[j] + 32768u;
+                uint32_t s = __umul24(18u, hc[j]) + 32768u;      // 24-bit multiply-add (full rate)
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 5) % 6][j]), W45, s, false);
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 3) % 6][j]), W23, s, false);
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 1) % 6][j]), W01, s, false);

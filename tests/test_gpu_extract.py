@@ -250,3 +250,17 @@ def test_small_feature_budget_and_tiny_levels():
         _assert_features(kps_g, desc_g if desc_g is not None else np.zeros((0, 32), np.uint8), kps_o, desc_o)
         assert np.array_equal(ex.debug_level_counts(), orc.last_level_counts())
         ex.close()
+
+
+def test_randomised_soak():
+    """A short run of tools/soak_parity.py: random sizes, contents and extractor settings, every
+    keypoint field and descriptor byte identical to the oracle."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_parity.py"), "25", "3"], env=env,
+                       capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 mismatches" in r.stdout

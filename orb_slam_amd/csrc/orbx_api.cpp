@@ -3,6 +3,7 @@
 // orbx_kernels.hip / orbx_match.hip.  There is no CPU path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -63,6 +64,12 @@ struct orbx_ctx {
     FrameGeom g;
     SlideMap blur_map;
     FastLds fast_lds;
+    int mk_w = -1, mk_h = -1, mk_val = 0;   // last orbx_max_keypoints answer
+    // pinned staging arena of the host-buffer entry points
+    struct PinPending { void* dst; size_t off, bytes; };
+    uint8_t* pin = nullptr;
+    size_t pin_cap = 0, pin_used = 0;
+    std::vector<PinPending> pin_pending;
     DevBuf xtab, ytab, xtab4, ytab2, fast_cells;
 
     // per-batch working set
@@ -258,6 +265,83 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     return ORBX_OK;
 }
 
+// ---- host <-> device staging ------------------------------------------------------------------
+// Copies between the device and ordinary (pageable) host memory make the runtime pin the pages on
+// every call, about a millisecond each -- ten times one frame's GPU time.  All host-buffer entry
+// points therefore go through one pinned arena owned by the context: uploads are copied into it and
+// sent from there, downloads land in it and are copied out by finish() after the stream has drained.
+hipError_t arena_reserve(orbx_ctx* c, size_t bytes, size_t* off)
+{
+    const size_t need = (c->pin_used + bytes + 63) & ~(size_t)63;
+    if (need > c->pin_cap) {
+        // everything enqueued so far refers to the old block: drain it first
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+        for (const auto& pd : c->pin_pending) std::memcpy(pd.dst, c->pin + pd.off, pd.bytes);
+        c->pin_pending.clear();
+        c->pin_used = 0;
+        const size_t want = std::max(((bytes + 63) & ~(size_t)63) * 2, c->pin_cap * 2);
+        if (want > c->pin_cap || !c->pin) {
+            if (c->pin) (void)hipHostFree(c->pin);
+            c->pin = nullptr;
+            c->pin_cap = 0;
+            void* p = nullptr;
+            e = hipHostMalloc(&p, want, hipHostMallocDefault);
+            if (e != hipSuccess) return e;
+            c->pin = static_cast<uint8_t*>(p);
+            c->pin_cap = want;
+        }
+    }
+    *off = c->pin_used;
+    c->pin_used = (c->pin_used + bytes + 63) & ~(size_t)63;
+    return hipSuccess;
+}
+
+hipError_t h2d(orbx_ctx* c, void* dev, const void* host, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    size_t off;
+    hipError_t e = arena_reserve(c, bytes, &off);
+    if (e != hipSuccess) return e;
+    std::memcpy(c->pin + off, host, bytes);
+    return hipMemcpyAsync(dev, c->pin + off, bytes, hipMemcpyHostToDevice, c->stream);
+}
+
+// h rows of w bytes, source rows `stride` apart, packed tightly on the device
+hipError_t h2d_rows(orbx_ctx* c, void* dev, const uint8_t* host, size_t stride, size_t w, size_t h)
+{
+    if (w == 0 || h == 0) return hipSuccess;
+    size_t off;
+    hipError_t e = arena_reserve(c, w * h, &off);
+    if (e != hipSuccess) return e;
+    if (stride == w) std::memcpy(c->pin + off, host, w * h);
+    else for (size_t r = 0; r < h; r++) std::memcpy(c->pin + off + r * w, host + r * stride, w);
+    return hipMemcpyAsync(dev, c->pin + off, w * h, hipMemcpyHostToDevice, c->stream);
+}
+
+hipError_t d2h(orbx_ctx* c, void* host, const void* dev, size_t bytes)
+{
+    if (bytes == 0) return hipSuccess;
+    size_t off;
+    hipError_t e = arena_reserve(c, bytes, &off);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(c->pin + off, dev, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e != hipSuccess) return e;
+    c->pin_pending.push_back({host, off, bytes});
+    return hipSuccess;
+}
+
+// drains the stream and delivers the downloads
+hipError_t finish(orbx_ctx* c)
+{
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess)
+        for (const auto& pd : c->pin_pending) std::memcpy(pd.dst, c->pin + pd.off, pd.bytes);
+    c->pin_pending.clear();
+    c->pin_used = 0;
+    return e;
+}
+
 int check_frame_args(orbx_ctx* c, int nframes, int w, int h, int stride)
 {
     if (!c) return ORBX_ERR_INVALID;
@@ -321,13 +405,14 @@ void orbx_destroy(orbx_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)finish(c);
     DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11]};
     for (DevBuf* b : bufs) b->release();
+    if (c->pin) (void)hipHostFree(c->pin);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->events_ok)
         for (int i = 0; i < kEventSets; i++)
@@ -345,7 +430,7 @@ int orbx_set_stream(orbx_ctx* c, void* hip_stream)
 {
     if (!c) return ORBX_ERR_INVALID;
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
     return ORBX_OK;
 }
@@ -378,11 +463,16 @@ int orbx_get_tables(const orbx_ctx* c, float* scale, float* inv_scale, float* si
 int orbx_max_keypoints(orbx_ctx* c, int w, int h, int* max_kps)
 {
     if (!c || !max_kps) return ORBX_ERR_INVALID;
+    // per-frame callers ask this before every extraction: answer from the geometry in use, or from
+    // the last size asked about, before building tables for a new size
+    if (w == c->gw && h == c->gh) { *max_kps = c->g.kp_per_frame; return ORBX_OK; }
+    if (w == c->mk_w && h == c->mk_h) { *max_kps = c->mk_val; return ORBX_OK; }
     FrameGeom g;
     ResizeTables rt;
     const char* msg = "";
     int rc = build_geometry(c->p, w, h, g, rt, &msg);
     if (rc != ORBX_OK) return fail(c, rc, msg);
+    c->mk_w = w; c->mk_h = h; c->mk_val = g.kp_per_frame;
     *max_kps = g.kp_per_frame;
     return ORBX_OK;
 }
@@ -414,23 +504,22 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
     if (!imgs || !kps || !desc || !n_out || cap_per_frame < 1) return fail(c, ORBX_ERR_INVALID, "null buffer or cap < 1");
     HIPCHECK(c, hipSetDevice(c->device));
     const size_t fbytes = (size_t)w * h, n = (size_t)nframes;
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     HIPCHECK(c, c->in.ensure(n * fbytes));
     HIPCHECK(c, c->out_kps.ensure(n * cap_per_frame * sizeof(orbx_keypoint)));
     HIPCHECK(c, c->out_desc.ensure(n * cap_per_frame * 32));
     HIPCHECK(c, c->out_n.ensure(n * 4));
     for (int f = 0; f < nframes; f++) {
         if (!imgs[f]) return fail(c, ORBX_ERR_INVALID, "null frame pointer");
-        HIPCHECK(c, hipMemcpy2DAsync(c->in.as<uint8_t>() + f * fbytes, w, imgs[f], stride, w, h, hipMemcpyHostToDevice,
-                                     c->stream));
+        HIPCHECK(c, h2d_rows(c, c->in.as<uint8_t>() + f * fbytes, imgs[f], stride, w, h));
     }
     rc = run_batch(c, c->in.as<uint8_t>(), nframes, w, h, w, fbytes, c->out_kps.as<orbx_keypoint>(),
                    c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false);
     if (rc != ORBX_OK) return rc;
-    HIPCHECK(c, hipMemcpyAsync(n_out, c->out_n.p, n * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(kps, c->out_kps.p, n * cap_per_frame * sizeof(orbx_keypoint), hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(desc, c->out_desc.p, n * cap_per_frame * 32, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, n_out, c->out_n.p, n * 4));
+    HIPCHECK(c, d2h(c, kps, c->out_kps.p, n * cap_per_frame * sizeof(orbx_keypoint)));
+    HIPCHECK(c, d2h(c, desc, c->out_desc.p, n * cap_per_frame * 32));
+    HIPCHECK(c, finish(c));
     for (int f = 0; f < nframes; f++)
         if (n_out[f] > cap_per_frame) return fail(c, ORBX_ERR_CAPACITY, "cap_per_frame smaller than the number of keypoints");
     return ORBX_OK;
@@ -455,12 +544,12 @@ int orbx_compute_pyramid(orbx_ctx* c, const uint8_t* img, int w, int h, int stri
     if (rc != ORBX_OK) return rc;
     if (!img) return fail(c, ORBX_ERR_INVALID, "null image");
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     HIPCHECK(c, c->in.ensure((size_t)w * h));
-    HIPCHECK(c, hipMemcpy2DAsync(c->in.p, w, img, stride, w, h, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d_rows(c, c->in.as<uint8_t>(), img, stride, w, h));
     rc = run_batch(c, c->in.as<uint8_t>(), 1, w, h, w, (size_t)w * h, nullptr, nullptr, 0, nullptr, true);
     if (rc != ORBX_OK) return rc;
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -473,9 +562,9 @@ int orbx_pyramid_level(orbx_ctx* c, int frame, int level, const uint8_t** data, 
     HIPCHECK(c, hipSetDevice(c->device));
     if (c->h_pyr_frame != frame) {
         c->h_pyr.resize(c->g.pyr_frame_bytes);
-        HIPCHECK(c, hipMemcpyAsync(c->h_pyr.data(), c->pyr.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes,
-                                   c->g.pyr_frame_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, d2h(c, c->h_pyr.data(), c->pyr.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes,
+                                   c->g.pyr_frame_bytes));
+        HIPCHECK(c, finish(c));
         c->h_pyr_frame = frame;
     }
     const LevelGeom& L = c->g.lv[level];
@@ -496,9 +585,8 @@ int orbx_debug_candidates(orbx_ctx* c, int frame, int level, int32_t* xyr, int c
     const FrameGeom& g = c->g;
     const LevelGeom& L = g.lv[level];
     int cnt = 0;
-    HIPCHECK(c, hipMemcpyAsync(&cnt, c->level_ncand.as<int>() + (size_t)frame * kMaxLevels + level, 4,
-                               hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, &cnt, c->level_ncand.as<int>() + (size_t)frame * kMaxLevels + level, 4));
+    HIPCHECK(c, finish(c));
     *n = cnt;
     if (cnt > cap) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
     if (cnt == 0) return ORBX_OK;
@@ -506,9 +594,9 @@ int orbx_debug_candidates(orbx_ctx* c, int frame, int level, int32_t* xyr, int c
     std::vector<uint32_t> xy(cnt);
     std::vector<uint8_t> rs(cnt);
     const size_t base = (size_t)frame * g.keys_per_frame + L.key_base;
-    HIPCHECK(c, hipMemcpyAsync(xy.data(), c->key_xy.as<uint32_t>() + base, (size_t)cnt * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(rs.data(), c->key_resp.as<uint8_t>() + base, (size_t)cnt, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, xy.data(), c->key_xy.as<uint32_t>() + base, (size_t)cnt * 4));
+    HIPCHECK(c, d2h(c, rs.data(), c->key_resp.as<uint8_t>() + base, (size_t)cnt));
+    HIPCHECK(c, finish(c));
     for (int i = 0; i < cnt; i++) {
         xyr[3 * i] = (int32_t)(xy[i] & 0xffff);
         xyr[3 * i + 1] = (int32_t)(xy[i] >> 16);
@@ -524,9 +612,8 @@ int orbx_debug_level_counts(orbx_ctx* c, int frame, int32_t* counts)
     if (frame < 0 || frame >= c->last_nframes) return fail(c, ORBX_ERR_INVALID, "frame out of range");
     HIPCHECK(c, hipSetDevice(c->device));
     int32_t tmp[kMaxLevels];
-    HIPCHECK(c, hipMemcpyAsync(tmp, c->level_count.as<int>() + (size_t)frame * kMaxLevels, sizeof(tmp),
-                               hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, tmp, c->level_count.as<int>() + (size_t)frame * kMaxLevels, sizeof(tmp)));
+    HIPCHECK(c, finish(c));
     for (int l = 0; l < c->g.nlevels; l++) counts[l] = tmp[l];
     return ORBX_OK;
 }
@@ -543,7 +630,7 @@ int orbx_debug_blurred_level(orbx_ctx* c, int frame, int level, uint8_t* out, si
     const uint8_t* src = c->blur.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes + L.plane_off +
                          (size_t)kPadY * L.pitch + kPadX;
     HIPCHECK(c, hipMemcpy2DAsync(out, L.w, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -551,7 +638,7 @@ int orbx_stage_times(orbx_ctx* c, const char** names, float* total_ms, int32_t* 
 {
     if (!c) return ORBX_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)finish(c);
     for (int i = 0; i < kEventSets; i++) harvest(c, c->evs[i]);
     int n = ST_COUNT < cap ? ST_COUNT : cap;
     for (int s = 0; s < n; s++) {
@@ -566,7 +653,7 @@ int orbx_reset_stage_times(orbx_ctx* c)
 {
     if (!c) return ORBX_ERR_INVALID;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)finish(c);
     for (int i = 0; i < kEventSets; i++) harvest(c, c->evs[i]);
     for (int s = 0; s < ST_COUNT; s++) { c->stage_ms[s] = 0; c->stage_launches[s] = 0; }
     return ORBX_OK;
@@ -605,7 +692,7 @@ int orbx_match_bruteforce_device(orbx_ctx* c, const uint32_t* d_q, int Q, int q_
     if (tsplit > 1) {
         size_t need = (size_t)nbatch * tsplit * q_stride * 8;
         if (need > c->partial.bytes) {
-            HIPCHECK(c, hipStreamSynchronize(c->stream));
+            HIPCHECK(c, finish(c));
             HIPCHECK(c, c->partial.ensure(need));
         }
     }
@@ -623,21 +710,21 @@ int orbx_match_bruteforce(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t*
     if (Q == 0) return ORBX_OK;
     if (!q || !best_idx || !best_dist || !second_dist || (T > 0 && !t)) return fail(c, ORBX_ERR_INVALID, "null buffer");
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     HIPCHECK(c, c->m0.ensure((size_t)Q * 32));
     HIPCHECK(c, c->m1.ensure((size_t)(T > 0 ? T : 1) * 32));
     HIPCHECK(c, c->m2.ensure((size_t)Q * 4));
     HIPCHECK(c, c->m3.ensure((size_t)Q * 4));
     HIPCHECK(c, c->m4.ensure((size_t)Q * 4));
-    HIPCHECK(c, hipMemcpyAsync(c->m0.p, q, (size_t)Q * 32, hipMemcpyHostToDevice, c->stream));
-    if (T > 0) HIPCHECK(c, hipMemcpyAsync(c->m1.p, t, (size_t)T * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m0.p, q, (size_t)Q * 32));
+    if (T > 0) HIPCHECK(c, h2d(c, c->m1.p, t, (size_t)T * 32));
     int rc = orbx_match_bruteforce_device(c, c->m0.as<uint32_t>(), Q, Q, nullptr, c->m1.as<uint32_t>(), T, T, nullptr, 1,
                                           c->m2.as<int32_t>(), c->m3.as<int32_t>(), c->m4.as<int32_t>());
     if (rc != ORBX_OK) return rc;
-    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m2.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m3.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(second_dist, c->m4.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, best_idx, c->m2.p, (size_t)Q * 4));
+    HIPCHECK(c, d2h(c, best_dist, c->m3.p, (size_t)Q * 4));
+    HIPCHECK(c, d2h(c, second_dist, c->m4.p, (size_t)Q * 4));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -655,17 +742,17 @@ static int upload_csr(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, 
     for (int k = 0; k < ncand; k++)
         if (cand_idx[k] < 0 || cand_idx[k] >= T) return fail(c, ORBX_ERR_INVALID, "candidate index out of range");
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     HIPCHECK(c, c->m0.ensure((size_t)Q * 32));
     HIPCHECK(c, c->m1.ensure((size_t)(T > 0 ? T : 1) * 32));
     HIPCHECK(c, c->m5.ensure((size_t)(Q + 1) * 4));
     HIPCHECK(c, c->m6.ensure((size_t)(ncand > 0 ? ncand : 1) * 4));
     HIPCHECK(c, c->m7.ensure((size_t)(T > 0 ? T : 1) * 4));
-    HIPCHECK(c, hipMemcpyAsync(c->m0.p, q, (size_t)Q * 32, hipMemcpyHostToDevice, c->stream));
-    if (T > 0) HIPCHECK(c, hipMemcpyAsync(c->m1.p, t, (size_t)T * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->m5.p, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, c->stream));
-    if (ncand > 0) HIPCHECK(c, hipMemcpyAsync(c->m6.p, cand_idx, (size_t)ncand * 4, hipMemcpyHostToDevice, c->stream));
-    if (t_octave && T > 0) HIPCHECK(c, hipMemcpyAsync(c->m7.p, t_octave, (size_t)T * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m0.p, q, (size_t)Q * 32));
+    if (T > 0) HIPCHECK(c, h2d(c, c->m1.p, t, (size_t)T * 32));
+    HIPCHECK(c, h2d(c, c->m5.p, cand_off, (size_t)(Q + 1) * 4));
+    if (ncand > 0) HIPCHECK(c, h2d(c, c->m6.p, cand_idx, (size_t)ncand * 4));
+    if (t_octave && T > 0) HIPCHECK(c, h2d(c, c->m7.p, t_octave, (size_t)T * 4));
     *ncand_out = ncand;
     return ORBX_OK;
 }
@@ -690,12 +777,12 @@ int orbx_match_windowed(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t
                           t_octave ? c->m7.as<int32_t>() : nullptr, c->m2.as<int32_t>(), c->m3.as<int32_t>(),
                           c->m4.as<int32_t>(), c->m8.as<int32_t>(), c->m9.as<int32_t>(), c->stream);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m2.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m3.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(second_dist, c->m4.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    if (best_lvl) HIPCHECK(c, hipMemcpyAsync(best_lvl, c->m8.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    if (second_lvl) HIPCHECK(c, hipMemcpyAsync(second_lvl, c->m9.p, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, best_idx, c->m2.p, (size_t)Q * 4));
+    HIPCHECK(c, d2h(c, best_dist, c->m3.p, (size_t)Q * 4));
+    HIPCHECK(c, d2h(c, second_dist, c->m4.p, (size_t)Q * 4));
+    if (best_lvl) HIPCHECK(c, d2h(c, best_lvl, c->m8.p, (size_t)Q * 4));
+    if (second_lvl) HIPCHECK(c, d2h(c, second_lvl, c->m9.p, (size_t)Q * 4));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -714,8 +801,8 @@ int orbx_hamming_csr(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, i
     launch_hamming_csr(c->m0.as<uint32_t>(), Q, c->m1.as<uint32_t>(), c->m5.as<int32_t>(), c->m6.as<int32_t>(),
                        c->m2.as<uint16_t>(), c->stream);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(dist_out, c->m2.p, (size_t)ncand * 2, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, dist_out, c->m2.p, (size_t)ncand * 2));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -751,7 +838,7 @@ int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, 
         if (kr[i].octave < 0 || kr[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "right keypoint octave out of range");
     const int stride = nl > nr ? nl : nr;
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     const size_t S = (size_t)stride;
     HIPCHECK(c, c->m0.ensure(S * sizeof(orbx_keypoint)));
     HIPCHECK(c, c->m1.ensure(S * 32));
@@ -763,25 +850,25 @@ int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, 
     HIPCHECK(c, c->m7.ensure(S * 4));
     HIPCHECK(c, c->m8.ensure(S * 4));
     int32_t counts[3] = {nl, nr, 0};
-    HIPCHECK(c, hipMemcpyAsync(c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->m1.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint)));
+    HIPCHECK(c, h2d(c, c->m1.p, dl, (size_t)nl * 32));
     if (nr > 0) {
-        HIPCHECK(c, hipMemcpyAsync(c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(c->m3.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, h2d(c, c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint)));
+        HIPCHECK(c, h2d(c, c->m3.p, dr, (size_t)nr * 32));
     }
-    HIPCHECK(c, hipMemcpyAsync(c->m4.p, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m4.p, counts, sizeof(counts)));
     int rc = orbx_stereo_match_device(c, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
                                       c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1, stride,
                                       nrows, mbf, mb, min_x, c->m5.as<int32_t>(), c->m6.as<int32_t>(), c->m7.as<float>(),
                                       c->m8.as<float>(), c->m4.as<int32_t>() + 2);
     if (rc != ORBX_OK) return rc;
     int32_t nm = 0;
-    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m5.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m6.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(u_right, c->m7.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(depth, c->m8.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(&nm, c->m4.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, best_idx, c->m5.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, best_dist, c->m6.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, u_right, c->m7.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, depth, c->m8.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, &nm, c->m4.as<int32_t>() + 2, 4));
+    HIPCHECK(c, finish(c));
     *nmatched = nm;
     return ORBX_OK;
 }
@@ -832,7 +919,7 @@ int orbx_stereo_match_sad(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* kl, con
         if (kl[i].octave < 0 || kl[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "left keypoint octave out of range");
     const int stride = nl > nr ? nl : nr;
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     HIPCHECK(c, hipStreamSynchronize(r->stream));
     const size_t S = (size_t)stride;
     HIPCHECK(c, c->m0.ensure(S * sizeof(orbx_keypoint)));
@@ -845,25 +932,25 @@ int orbx_stereo_match_sad(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* kl, con
     HIPCHECK(c, c->m7.ensure(S * 4));
     HIPCHECK(c, c->m8.ensure(S * 4));
     int32_t counts[3] = {nl, nr, 0};
-    HIPCHECK(c, hipMemcpyAsync(c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->m1.p, dl, (size_t)nl * 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint)));
+    HIPCHECK(c, h2d(c, c->m1.p, dl, (size_t)nl * 32));
     if (nr > 0) {
-        HIPCHECK(c, hipMemcpyAsync(c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
-        HIPCHECK(c, hipMemcpyAsync(c->m3.p, dr, (size_t)nr * 32, hipMemcpyHostToDevice, c->stream));
+        HIPCHECK(c, h2d(c, c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint)));
+        HIPCHECK(c, h2d(c, c->m3.p, dr, (size_t)nr * 32));
     }
-    HIPCHECK(c, hipMemcpyAsync(c->m4.p, counts, sizeof(counts), hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, c->m4.p, counts, sizeof(counts)));
     int rc = orbx_stereo_match_sad_device(c, r, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
                                           c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1,
                                           stride, mbf, mb, c->m5.as<int32_t>(), c->m6.as<int32_t>(), c->m7.as<float>(),
                                           c->m8.as<float>(), c->m4.as<int32_t>() + 2);
     if (rc != ORBX_OK) return rc;
     int32_t nm = 0;
-    HIPCHECK(c, hipMemcpyAsync(best_idx, c->m5.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(best_dist, c->m6.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(u_right, c->m7.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(depth, c->m8.p, (size_t)nl * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(&nm, c->m4.as<int32_t>() + 2, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, best_idx, c->m5.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, best_dist, c->m6.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, u_right, c->m7.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, depth, c->m8.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, &nm, c->m4.as<int32_t>() + 2, 4));
+    HIPCHECK(c, finish(c));
     *nmatched = nm;
     return ORBX_OK;
 }
@@ -874,7 +961,7 @@ static int grid_prepare(orbx_ctx* c, const orbx_keypoint* d_kps, const int32_t* 
     if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
     const size_t need_s = (size_t)nbatch * (kFrameGridCells + 1) * 4, need_l = (size_t)nbatch * stride * 4;
     if (need_s > c->grid_start.bytes || need_l > c->grid_list.bytes) {
-        HIPCHECK(c, hipStreamSynchronize(c->stream));
+        HIPCHECK(c, finish(c));
         HIPCHECK(c, c->grid_start.ensure(need_s));
         HIPCHECK(c, c->grid_list.ensure(need_l));
     }
@@ -912,21 +999,21 @@ static int grid_upload(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* de
 {
     if (!kps || !qx || !qy || !qr || !qmin || !qmax) return fail(c, ORBX_ERR_INVALID, "null buffer");
     HIPCHECK(c, hipSetDevice(c->device));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, finish(c));
     const size_t n = (size_t)(N > 0 ? N : 1), q = (size_t)Q;
     HIPCHECK(c, c->gq[0].ensure(n * sizeof(orbx_keypoint)));
     HIPCHECK(c, c->gq[1].ensure(n * 32));
     for (int k = 2; k <= 6; k++) HIPCHECK(c, c->gq[k].ensure(q * 4));
     HIPCHECK(c, c->gq[7].ensure(q * 32));
     for (int k = 8; k <= 11; k++) HIPCHECK(c, c->gq[k].ensure((q + 1) * 4 * 2));
-    if (N > 0) HIPCHECK(c, hipMemcpyAsync(c->gq[0].p, kps, (size_t)N * sizeof(orbx_keypoint), hipMemcpyHostToDevice, c->stream));
-    if (N > 0 && desc) HIPCHECK(c, hipMemcpyAsync(c->gq[1].p, desc, (size_t)N * 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->gq[2].p, qx, q * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->gq[3].p, qy, q * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->gq[4].p, qr, q * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->gq[5].p, qmin, q * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(c->gq[6].p, qmax, q * 4, hipMemcpyHostToDevice, c->stream));
-    if (qdesc) HIPCHECK(c, hipMemcpyAsync(c->gq[7].p, qdesc, q * 32, hipMemcpyHostToDevice, c->stream));
+    if (N > 0) HIPCHECK(c, h2d(c, c->gq[0].p, kps, (size_t)N * sizeof(orbx_keypoint)));
+    if (N > 0 && desc) HIPCHECK(c, h2d(c, c->gq[1].p, desc, (size_t)N * 32));
+    HIPCHECK(c, h2d(c, c->gq[2].p, qx, q * 4));
+    HIPCHECK(c, h2d(c, c->gq[3].p, qy, q * 4));
+    HIPCHECK(c, h2d(c, c->gq[4].p, qr, q * 4));
+    HIPCHECK(c, h2d(c, c->gq[5].p, qmin, q * 4));
+    HIPCHECK(c, h2d(c, c->gq[6].p, qmax, q * 4));
+    if (qdesc) HIPCHECK(c, h2d(c, c->gq[7].p, qdesc, q * 32));
     return ORBX_OK;
 }
 
@@ -952,13 +1039,13 @@ int orbx_grid_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc
                                  o, o + Q + 1, o2, o2 + Q + 1, o3, o3 + Q + 1);
     if (rc != ORBX_OK) return rc;
     const size_t qb = (size_t)Q * 4;
-    HIPCHECK(c, hipMemcpyAsync(best_idx, o, qb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(best_dist, o + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipMemcpyAsync(second_dist, o2, qb, hipMemcpyDeviceToHost, c->stream));
-    if (best_lvl) HIPCHECK(c, hipMemcpyAsync(best_lvl, o2 + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
-    if (second_lvl) HIPCHECK(c, hipMemcpyAsync(second_lvl, o3, qb, hipMemcpyDeviceToHost, c->stream));
-    if (ncand) HIPCHECK(c, hipMemcpyAsync(ncand, o3 + Q + 1, qb, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, best_idx, o, qb));
+    HIPCHECK(c, d2h(c, best_dist, o + Q + 1, qb));
+    HIPCHECK(c, d2h(c, second_dist, o2, qb));
+    if (best_lvl) HIPCHECK(c, d2h(c, best_lvl, o2 + Q + 1, qb));
+    if (second_lvl) HIPCHECK(c, d2h(c, second_lvl, o3, qb));
+    if (ncand) HIPCHECK(c, d2h(c, ncand, o3 + Q + 1, qb));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -986,8 +1073,8 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
                        nullptr, nullptr, d_cnt, nullptr, nullptr, c->stream);
     HIPCHECK(c, hipGetLastError());
     std::vector<int32_t> cnt(Q);
-    HIPCHECK(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)Q * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, cnt.data(), d_cnt, (size_t)Q * 4));
+    HIPCHECK(c, finish(c));
     long long sum = 0;
     for (int q = 0; q < Q; q++) { cand_off[q] = (int32_t)sum; sum += cnt[q]; }
     if (sum > 0x7fffffffLL) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates");
@@ -997,14 +1084,14 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
     if (!cand_idx || cap < sum) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
     // pass 2: fill
     HIPCHECK(c, c->gq[11].ensure((size_t)sum * 4));
-    HIPCHECK(c, hipMemcpyAsync(d_off, cand_off, (size_t)(Q + 1) * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, d_off, cand_off, (size_t)(Q + 1) * 4));
     launch_grid_search(c->gq[0].as<orbx_keypoint>(), nullptr, c->grid_start.as<int>(), c->grid_list.as<int>(), stride, 1,
                        c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(), c->gq[5].as<int32_t>(),
                        c->gq[6].as<int32_t>(), nullptr, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr, nullptr, nullptr,
                        nullptr, nullptr, nullptr, d_off, c->gq[11].as<int32_t>(), c->stream);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(cand_idx, c->gq[11].p, (size_t)sum * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, cand_idx, c->gq[11].p, (size_t)sum * 4));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 
@@ -1069,11 +1156,11 @@ int orbx_undistort_keypoints(orbx_ctx* c, const orbx_keypoint* kps_in, int n, co
     const size_t bytes = (size_t)n * sizeof(orbx_keypoint);
     HIPCHECK(c, c->gq[0].ensure(bytes));
     orbx_keypoint* d = c->gq[0].as<orbx_keypoint>();
-    HIPCHECK(c, hipMemcpyAsync(d, kps_in, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHECK(c, h2d(c, d, kps_in, bytes));
     launch_undistort(d, nullptr, n, n, 1, m, d, c->stream);
     HIPCHECK(c, hipGetLastError());
-    HIPCHECK(c, hipMemcpyAsync(kps_out, d, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    HIPCHECK(c, d2h(c, kps_out, d, bytes));
+    HIPCHECK(c, finish(c));
     return ORBX_OK;
 }
 

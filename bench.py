@@ -226,6 +226,20 @@ def main():
                          "ms_per_call": round(dt_ / reps * 1e3, 4)}
         out["hamming"] = res
 
+    # ---- latency of one frame, as an online tracker calls it (reported beside the throughput; not `value`) ----
+    if rank == 0:
+        ex.set_stream(None)
+        one = host[0]
+        for _ in range(10):
+            ex(one)
+        lat = []
+        for i in range(100):
+            t0 = time.perf_counter()
+            ex(host[i % min(B, 8)])
+            lat.append(time.perf_counter() - t0)
+        out["single_frame"] = {"host_buffers_median_us": round(float(np.median(lat)) * 1e6, 1),
+                               "note": "orbx_extract on one 752x480 host image: upload, kernels, download, synchronise"}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(host[:min(B, 256)])
     elif rank == 0:

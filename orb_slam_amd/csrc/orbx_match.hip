@@ -9,6 +9,7 @@
 // Distances are popcounts of XORed 32-bit words (v_bcnt_u32_b32 accumulates).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "../../include/orbx.h"
 #include "orbx_common.hpp"
@@ -101,6 +102,178 @@ __global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict_
     second_dist[o] = (int32_t)(second >> 22);
 }
 
+// ---------------------------------------------------------------------------
+// Brute force on the matrix cores.  Hamming(a, b) = |a| + |b| - 2 <a, b> for bit vectors, and the
+// 256-bit inner products of 32 train x 32 query descriptors are one chain of eight
+// v_mfma_i32_32x32x32_i8 over bits expanded to 0/1 bytes.  With the trains as the A operand and
+// the queries as B, lane l of the 32x32 result holds query l & 31 against 16 trains (rows
+// (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)), so the (best, second) update is lane-local: three
+// vector instructions per pair instead of the ~19 of the xor/popcount form.  A wavefront keeps the
+// expanded bytes of kMfmaQT * 32 queries in registers and streams the train tiles past them.
+// The key field during the sweep is |b| - 2 <a, b> + 256 (|a| is the same for every candidate of
+// a query and is added at the end); key order, and therefore the tie rule "smallest distance, then
+// smallest index", is that of k_match_bruteforce.
+// ---------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+constexpr int kMfmaQT = 2;              // query tiles (of 32) per wavefront
+
+// 16 bits -> 16 bytes of 0/1 (bit i -> byte i)
+__device__ __forceinline__ v4i_t expand16(uint32_t bits16)
+{
+    v4i_t r;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        r[q] = (int)(__umul24((bits16 >> (4 * q)) & 0xfu, 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+// grid (ceil(q_stride / (kMfmaWaves * 32 * kMfmaQT)), tsplit, nbatch); workgroup = kMfmaWaves wavefronts, each
+// with its own 32 * kMfmaQT queries, all sweeping the same train tiles.  Expanding a train tile to bytes is
+// the largest fixed cost per tile, so the wavefronts split it (8 / kMfmaWaves of the eight k-steps each), park the
+// fragments and the tile's key bases in LDS (double-buffered, one barrier per tile) and every wavefront
+// reads them back.
+constexpr int kMfmaWaves = 4;
+constexpr int kMfmaSteps = 8 / kMfmaWaves;      // k-steps each wavefront expands
+
+template <bool kPartial>
+__device__ __forceinline__ void mfma_sweep(const v4i_t* __restrict__ a_frag, const uint32_t* __restrict__ krow, int lane,
+                                           int half, const v4i_t (&bq)[kMfmaQT][8], int valid_rows,
+                                           uint32_t (&best)[kMfmaQT], uint32_t (&second)[kMfmaQT])
+{
+    v16i_t acc[kMfmaQT];
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+        const v4i_t a = a_frag[s * 64 + lane];
+#pragma unroll
+        for (int qt = 0; qt < kMfmaQT; qt++) {
+            if (s == 0) {
+                const v16i_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], zero, 0, 0, 0);
+            } else {
+                acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], acc[qt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        // rows 8g + 4 * half + {0, 1, 2, 3} of the tile are registers 4g .. 4g + 3 of this lane
+        const uint4 K4 = *reinterpret_cast<const uint4*>(krow + 8 * g + 4 * half);
+        const uint32_t K[4] = {K4.x, K4.y, K4.z, K4.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
+#pragma unroll
+            for (int qt = 0; qt < kMfmaQT; qt++) {
+                // key = (|b| + 256 - 2 dot) << 22 | index
+                uint32_t key = (uint32_t)__mul24(acc[qt][4 * g + i], -8388608) + K[i];
+                if (kPartial) key = ok ? key : 0xffffffffu;
+                push_key(best[qt], second[qt], key);
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64 * kMfmaWaves) void k_match_bruteforce_mfma(
+    const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
+    int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
+    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    __shared__ v4i_t s_a[2][8 * 64];          // expanded train fragments: [buffer][k-step][lane]
+    __shared__ __align__(16) uint32_t s_k[2][32];   // key base of every train row of the tile
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+    const int nQ = nq ? min(nq[b], q_stride) : Q;
+    const int nT = nt ? nt[b] : T;
+    const int q0 = (blockIdx.x * kMfmaWaves + wave) * (32 * kMfmaQT);
+    if (blockIdx.x * kMfmaWaves * (32 * kMfmaQT) >= nQ) return;         // whole workgroup past the queries
+    const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
+    const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
+    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
+
+    // queries: this lane's query of every tile, expanded once (B operand: k-set `half`, column r)
+    v4i_t bq[kMfmaQT][8];
+    int pa[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) {
+        const int qi = min(q0 + 32 * qt + r, nQ - 1);
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
+        const uint4 x = qp[0], y = qp[1];
+        const uint32_t qd[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        pa[qt] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            bq[qt][s] = expand16((qd[s] >> (16 * half)) & 0xffffu);
+            pa[qt] += __popc(qd[s]);
+        }
+    }
+    uint32_t best[kMfmaQT], second[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) { best[qt] = 0xffffffffu; second[qt] = 0xffffffffu; }
+
+    // train row r of a tile: this wavefront needs the dwords of its own k-steps; wavefront 0 reads the whole
+    // descriptor for |b|
+    const uint32_t* tp = t + (size_t)b * t_stride * 8;
+    uint32_t mine[kMfmaSteps] = {};
+    uint4 x = make_uint4(0, 0, 0, 0), y = x;
+    auto fetch = [&](int j) {
+        const int ti = min(j + r, j1 - 1);
+        if (wave == 0) {
+            x = reinterpret_cast<const uint4*>(tp)[2 * ti];
+            y = reinterpret_cast<const uint4*>(tp)[2 * ti + 1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kMfmaSteps; k++) mine[k] = tp[8 * (size_t)ti + kMfmaSteps * wave + k];
+        }
+    };
+    if (j0 < j1) fetch(j0);
+    int buf = 0;
+    for (int j = j0; j < j1; j += 32, buf ^= 1) {
+        if (wave == 0) {
+            mine[0] = x.x;
+            if (kMfmaSteps > 1) mine[kMfmaSteps - 1] = x.y;
+            if (half == 0) {
+                const int pb = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
+                s_k[buf][r] = ((uint32_t)(pb + 256) << 22) | (uint32_t)(j + r);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kMfmaSteps; k++)
+            s_a[buf][(kMfmaSteps * wave + k) * 64 + lane] = expand16((mine[k] >> (16 * half)) & 0xffffu);
+        if (j + 32 < j1) fetch(j + 32);
+        __syncthreads();
+        if (active) {
+            if (j + 32 <= j1) mfma_sweep<false>(s_a[buf], s_k[buf], lane, half, bq, 32, best, second);
+            else mfma_sweep<true>(s_a[buf], s_k[buf], lane, half, bq, j1 - j, best, second);
+        }
+    }
+    if (!active) return;
+
+    // the two halves of the wavefront saw different trains of the same query: merge, then restore |a|
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) {
+        const uint32_t ob = __shfl_xor(best[qt], 32, 64), os = __shfl_xor(second[qt], 32, 64);
+        push_key(best[qt], second[qt], ob);
+        push_key(best[qt], second[qt], os);
+        const int qi = q0 + 32 * qt + r;
+        if (half != 0 || qi >= nQ) continue;
+        // field -> true distance: + |a| - 256; "no candidate" stays the sentinel of the scalar kernel
+        const uint32_t fix = (uint32_t)(pa[qt] - 256) << 22;
+        const uint32_t kb = best[qt] == 0xffffffffu ? kKeyNone : best[qt] + fix;
+        const uint32_t ks = second[qt] == 0xffffffffu ? kKeyNone : second[qt] + fix;
+        const size_t o = (size_t)b * q_stride + qi;
+        if (tsplit == 1) {
+            best_idx[o] = (kb >> 22) >= 256u ? -1 : (int32_t)(kb & 0x3FFFFFu);
+            best_dist[o] = (int32_t)(kb >> 22);
+            second_dist[o] = (int32_t)(ks >> 22);
+        } else {
+            uint32_t* p = partial + (((size_t)b * tsplit + blockIdx.y) * q_stride + qi) * 2;
+            p[0] = kb;
+            p[1] = ks;
+        }
+    }
+}
+
 int match_bruteforce_tsplit(int Q, int T, int nbatch)
 {
     // enough workgroups to fill 256 CUs a few times over, chunks of >= 256 train descriptors
@@ -119,9 +292,18 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
                              int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
                              int32_t* d_second_dist, hipStream_t s)
 {
-    dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
-    hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
-                       tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+    // the matrix-core sweep pays from a few thousand pairs per query tile on; tiny problems keep the scalar form
+    static const bool no_mfma = getenv("ORBX_MATCH_NO_MFMA") != nullptr;
+    if (!no_mfma && T >= 64 && q_stride >= 32) {
+        const int per_wg = kMfmaWaves * 32 * kMfmaQT;
+        dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
+        hipLaunchKernelGGL(k_match_bruteforce_mfma, grid, dim3(64 * kMfmaWaves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
+                           tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+    } else {
+        dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
+        hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
+                           tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+    }
     if (tsplit > 1) {
         dim3 g2((q_stride + 255) / 256, nbatch);
         hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, d_partial, Q, q_stride, d_nq, tsplit, d_best_idx,

@@ -58,6 +58,36 @@ def test_bruteforce_all_bits_differ(matcher, oracle):
     assert (bi == -1).all() and (bd == 256).all()
 
 
+def test_bruteforce_extreme_popcounts(matcher, oracle):
+    """Sizes that take the matrix-core sweep, with the extreme cases of its distance identity
+    |a| + |b| - 2<a,b>: empty and full descriptors, complements (distance 256, never a match),
+    identical sets, a train count that is no multiple of the 32-row tile, ragged query count."""
+    rng = np.random.default_rng(21)
+    Q, T = 97, 333
+    q = rng.integers(0, 256, (Q, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (T, 32), dtype=np.uint8)
+    q[0] = 0
+    q[1] = 255
+    t[0] = 255
+    t[1] = 0
+    t[2] = ~q[2]            # exact complement
+    t[40] = q[5]
+    t[300] = q[5]           # duplicate exact match: lower index wins, second distance 0
+    bi, bd, sd = matcher.match_bruteforce(q, t)
+    oi, od, os_ = oracle.match_bruteforce(q, t)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_)
+    assert bi[5] == 40 and bd[5] == 0 and sd[5] == 0
+    # every train the complement of every query: nothing matches
+    qq = np.zeros((64, 32), np.uint8)
+    tt = np.full((96, 32), 255, np.uint8)
+    bi, bd, sd = matcher.match_bruteforce(qq, tt)
+    assert (bi == -1).all() and (bd == 256).all() and (sd == 256).all()
+    # a set against itself
+    bi, bd, sd = matcher.match_bruteforce(t, t)
+    oi, od, os_ = oracle.match_bruteforce(t, t)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_)
+
+
 def _random_csr(rng, Q, T, maxc):
     counts = rng.integers(0, maxc + 1, Q)
     counts[rng.integers(0, Q, max(1, Q // 10))] = 0        # ragged: empty lists

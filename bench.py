@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--frames", type=int, default=256, help="frames per batch (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-match", action="store_true")
+    ap.add_argument("--single-frame", action="store_true",
+                    help="also time orbx_extract on one host frame (adds small launches of every kernel, which\n"
+                         "would dilute per-kernel averages in a profile of the default command)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -227,7 +230,7 @@ def main():
         out["hamming"] = res
 
     # ---- latency of one frame, as an online tracker calls it (reported beside the throughput; not `value`) ----
-    if rank == 0:
+    if rank == 0 and args.single_frame:
         ex.set_stream(None)
         one = host[0]
         for _ in range(10):

@@ -380,7 +380,7 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scaleFactor, int nlevels, i
     c->stream = c->own_stream;
     int taps[7];
     gauss7_taps(taps);
-    if (upload_constant_tables(c->p.patch_du, c->p.patch_dv, taps, c->p.umax, c->stream) != 0) {
+    if (upload_constant_tables(taps, c->p.umax, c->stream) != 0) {
         (void)hipStreamDestroy(c->own_stream);
         delete c;
         return ORBX_ERR_HIP;

@@ -29,21 +29,16 @@ namespace orbx {
 __constant__ int8_t c_pattern[256 * 4] = {
 #include "orb_pattern.inc"
 };
-__constant__ int8_t c_patch_du[kPatchPixels + 3];
-__constant__ int8_t c_patch_dv[kPatchPixels + 3];
-__constant__ int c_gauss[8];
 __constant__ int c_umax[16];
 
-int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, const int* umax16, hipStream_t s)
+// the blur kernel has the 8.8 fixed-point taps of cv::getGaussianKernel(7, 2) compiled in
+const int kGaussTaps[7] = {18, 34, 49, 55, 49, 34, 18};
+
+int upload_constant_tables(const int* gauss7, const int* umax16, hipStream_t s)
 {
-    hipError_t e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int), 0, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_du), du, kPatchPixels, 0, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_patch_dv), dv, kPatchPixels, 0, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_gauss), gauss7, 7 * sizeof(int), 0, hipMemcpyHostToDevice, s);
+    for (int i = 0; i < 7; i++)
+        if (gauss7[i] != kGaussTaps[i]) return -1;      // the host derivation and the kernel must agree
+    hipError_t e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_umax), umax16, 16 * sizeof(int), 0, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return (int)e;
     return (int)hipStreamSynchronize(s);
 }

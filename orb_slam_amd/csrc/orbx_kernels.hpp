@@ -26,7 +26,7 @@ struct FastLds {
 
 struct ScaleTab { float v[kMaxLevels]; };
 
-int upload_constant_tables(const int8_t* du, const int8_t* dv, const int* gauss7, const int* umax16, hipStream_t s);
+int upload_constant_tables(const int* gauss7, const int* umax16, hipStream_t s);
 
 void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8_t* pyr, const FrameGeom& g,
                        int nframes, hipStream_t s);

@@ -64,7 +64,7 @@ public:
                            descriptors.data(), cap, &n));
         keypoints.resize(n);
         descriptors.resize((size_t)n * 32);
-        refresh_pyramid();
+        if (mirrorPyramid) refresh_pyramid();
     }
 
     // include/ORBextractor.h:143 (public: the detection-I/O path calls it on its own)
@@ -87,6 +87,10 @@ public:
     // un-blurred levels of the last call, each surrounded by >= 19 REFLECT_101
     // border pixels at the same step; valid until the next call on this object.
     std::vector<ImageView> mvImagePyramid;
+    // Only the classic stereo matcher reads mvImagePyramid on the host (src/Frame.cc:991,1089,1111).  A caller that
+    // does not (monocular, RGB-D, or stereo through orbx_stereo_match_sad, which reads the pyramid on the device)
+    // clears this flag and saves the 1.5 MB download per frame; the views then stay empty.
+    bool mirrorPyramid = true;
 
     orbx_ctx* context() { return ctx_; }
 

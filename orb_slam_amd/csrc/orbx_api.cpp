@@ -84,7 +84,8 @@ struct orbx_ctx {
 
     int last_nframes = 0;
     bool have_pyramid = false, have_features = false;
-    std::vector<uint8_t> h_pyr;
+    uint8_t* h_pyr = nullptr;      // pinned host mirror of one frame's pyramid (orbx_pyramid_level)
+    size_t h_pyr_bytes = 0;
     int h_pyr_frame = -1;
 
     // stage timing
@@ -283,6 +284,7 @@ hipError_t arena_reserve(orbx_ctx* c, size_t bytes, size_t* off)
         const size_t want = std::max(((bytes + 63) & ~(size_t)63) * 2, c->pin_cap * 2);
         if (want > c->pin_cap || !c->pin) {
             if (c->pin) (void)hipHostFree(c->pin);
+    if (c->h_pyr) (void)hipHostFree(c->h_pyr);
             c->pin = nullptr;
             c->pin_cap = 0;
             void* p = nullptr;
@@ -561,14 +563,24 @@ int orbx_pyramid_level(orbx_ctx* c, int frame, int level, const uint8_t** data, 
         return fail(c, ORBX_ERR_INVALID, "frame or level out of range");
     HIPCHECK(c, hipSetDevice(c->device));
     if (c->h_pyr_frame != frame) {
-        c->h_pyr.resize(c->g.pyr_frame_bytes);
-        HIPCHECK(c, d2h(c, c->h_pyr.data(), c->pyr.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes,
-                                   c->g.pyr_frame_bytes));
+        // the mirror is pinned memory of its own: one direct copy, nothing staged
+        if (c->h_pyr_bytes < c->g.pyr_frame_bytes) {
+            HIPCHECK(c, finish(c));
+            if (c->h_pyr) (void)hipHostFree(c->h_pyr);
+            c->h_pyr = nullptr;
+            c->h_pyr_bytes = 0;
+            void* p = nullptr;
+            HIPCHECK(c, hipHostMalloc(&p, c->g.pyr_frame_bytes, hipHostMallocDefault));
+            c->h_pyr = static_cast<uint8_t*>(p);
+            c->h_pyr_bytes = c->g.pyr_frame_bytes;
+        }
+        HIPCHECK(c, hipMemcpyAsync(c->h_pyr, c->pyr.as<uint8_t>() + (size_t)frame * c->g.pyr_frame_bytes,
+                                   c->g.pyr_frame_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHECK(c, finish(c));
         c->h_pyr_frame = frame;
     }
     const LevelGeom& L = c->g.lv[level];
-    *data = c->h_pyr.data() + L.plane_off + (size_t)kPadY * L.pitch + kPadX;
+    *data = c->h_pyr + L.plane_off + (size_t)kPadY * L.pitch + kPadX;
     if (w) *w = L.w;
     if (h) *h = L.h;
     if (stride) *stride = L.pitch;

@@ -3,6 +3,7 @@
 // reference's operator() (src/Frame.cc:553-559), and dumps the results.
 //   host_extract <raw_u8_file> <w> <h> <out_file>
 // out_file: int32 n, int32 nlevels, nlevels x (int32 w, int32 h), n x 28 bytes keypoints, n x 32 bytes descriptors
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -38,6 +39,16 @@ int main(int argc, char** argv)
         std::fwrite(&px, 1, 1, o);
         std::fclose(o);
         std::printf("%d keypoints, scale[1]=%.6f\n", n, ex->GetScaleFactors()[1]);
+        // per-call latency of the drop-in class, with and without the host mirror of the pyramid
+        for (int mirror = 1; mirror >= 0; mirror--) {
+            ex->mirrorPyramid = mirror != 0;
+            for (int i = 0; i < 20; i++) (*ex)(orbx::ImageView(img.data(), w, h, (size_t)w), orbx::ImageView(), kps, desc);
+            const auto t0 = std::chrono::steady_clock::now();
+            const int reps = 200;
+            for (int i = 0; i < reps; i++) (*ex)(orbx::ImageView(img.data(), w, h, (size_t)w), orbx::ImageView(), kps, desc);
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+            std::printf("operator() %s pyramid mirror: %.0f us per frame (%d keypoints)\n", mirror ? "with" : "without", us, (int)kps.size());
+        }
         delete ex;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "%s\n", e.what());

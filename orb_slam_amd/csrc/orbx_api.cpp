@@ -210,8 +210,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         c->ev_next = (c->ev_next + 1) % kEventSets;
         harvest(c, *es);
     }
-    const char* e_ov = getenv("ORBX_OVERLAP");
-    const bool want_overlap = e_ov && atoi(e_ov) != 0;
+    static const bool want_overlap = getenv("ORBX_OVERLAP") && atoi(getenv("ORBX_OVERLAP")) != 0;
     const bool overlap = c->aux_stream && want_overlap && !pyramid_only;
     if (es) es->chained = !overlap;
     auto t0 = [&](int i, hipStream_t q) { if (es && (i == 0 || !es->chained)) (void)hipEventRecord(es->start[i], q); };
@@ -221,7 +220,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     launch_pyr_level0(d_imgs, stride, frame_stride, c->pyr.as<uint8_t>(), g, nframes, s);
     t1(ST_PYR0, s);
     t0(ST_RESIZE, s);
-    const bool slide = g.resize_slide_ok && !getenv("ORBX_OLD_RESIZE");
+    static const bool old_resize = getenv("ORBX_OLD_RESIZE") != nullptr;
+    const bool slide = g.resize_slide_ok && !old_resize;
     for (int l = 1; l < g.nlevels; l++) {
         if (slide) launch_resize_slide(c->pyr.as<uint8_t>(), g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
         else launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
@@ -284,7 +284,6 @@ hipError_t arena_reserve(orbx_ctx* c, size_t bytes, size_t* off)
         const size_t want = std::max(((bytes + 63) & ~(size_t)63) * 2, c->pin_cap * 2);
         if (want > c->pin_cap || !c->pin) {
             if (c->pin) (void)hipHostFree(c->pin);
-    if (c->h_pyr) (void)hipHostFree(c->h_pyr);
             c->pin = nullptr;
             c->pin_cap = 0;
             void* p = nullptr;
@@ -415,6 +414,7 @@ void orbx_destroy(orbx_ctx* c)
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11]};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
+    if (c->h_pyr) (void)hipHostFree(c->h_pyr);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream);
     if (c->events_ok)
         for (int i = 0; i < kEventSets; i++)

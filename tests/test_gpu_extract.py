@@ -188,6 +188,26 @@ def test_compute_pyramid_only(gpu, oracle, euroc_right):
         assert np.array_equal(gpu.pyramid_level(l, border=19), oracle.pyramid_plane(l))
 
 
+def test_pyramid_mirror_survives_staging_growth(oracle, euroc_left):
+    """The host mirror of the pyramid and the staging area for host buffers are separate
+    allocations: a call that makes the staging area grow must not disturb the mirror."""
+    from orb_slam_amd import ORBextractor
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    try:
+        small = np.ascontiguousarray(euroc_left[:240, :320])
+        ex(small)
+        first = ex.pyramid_level(0, border=19).copy()
+        ex.extract_batch(np.stack([euroc_left] * 6))     # far larger uploads and downloads than before
+        ex(small)
+        assert np.array_equal(ex.pyramid_level(0, border=19), first)
+        oracle.compute_pyramid(euroc_left)
+        ex(euroc_left)
+        for l in range(8):
+            assert np.array_equal(ex.pyramid_level(l, border=19), oracle.pyramid_plane(l))
+    finally:
+        ex.close()
+
+
 def test_cpp_host_program(oracle, euroc_left, tmp_path):
     """The C++ host class (include/orbx_host.hpp) gives the same result as the oracle."""
     import os

@@ -79,9 +79,10 @@ struct FastCell {
     uint8_t cw, ch;      // tested area (0: empty cell)
     uint8_t ox;          // bytes between the tile's first dword and its first pixel
     uint8_t ndw;         // dwords per tile row
-    uint8_t rpr;         // whole cell rows one 64-lane round of the pretest covers (0: flat pixel order instead)
-    uint8_t pad8[3];
-    uint32_t pad;
+    uint8_t lpr;         // lanes per cell row in the pretest: ceil(cw / 4), four pixels per lane
+    uint8_t fast_rows;   // cell rows one 64-lane round of the pretest covers: 64 / lpr
+    uint8_t pad8[2];
+    uint32_t rcp_lpr;    // ceil(2^16 / lpr): lane / lpr = lane * rcp_lpr >> 16 for lane < 64
 };
 static_assert(sizeof(FastCell) == 32, "one s_load_dwordx8");
 

@@ -378,6 +378,41 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int pitch)
     return max(v - mnmx, mxmn - v) - 1;
 }
 
+// inclusive scan over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside each row of
+// 16 lanes (row_shr 1, 2, 4, 8 shifting zeros in), then the last lane of rows 0 and 2 is added to
+// rows 1 and 3 (row_bcast15), then lane 31 to rows 2 and 3 (row_bcast31)
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2, 3
+    return v;
+}
+
+// four pixels at a time for the FAST pretest: a dword of pixels split into its
+// even and odd bytes as pairs of 16-bit lanes, so that packed 16-bit min / max / saturating subtract
+// work on two pixels per instruction
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2_t even_bytes(uint32_t x) { return __builtin_bit_cast(us2_t, x & 0x00ff00ffu); }
+__device__ __forceinline__ us2_t odd_bytes(uint32_t x) { return __builtin_bit_cast(us2_t, __builtin_amdgcn_perm(0u, x, 0x0c030c01u)); }
+// the compiler turns min(x, 1) into compare + select + repack; keep it one instruction (b: both halves in an SGPR)
+__device__ __forceinline__ us2_t pk_min_u16(us2_t a, uint32_t b)
+{
+    us2_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+}
+// max(br, dk) of the compass test, clamped at 0, for two pixels
+__device__ __forceinline__ us2_t compass2(us2_t v, us2_t p0, us2_t p8, us2_t p4, us2_t p12)
+{
+    const us2_t hi = __builtin_elementwise_min(__builtin_elementwise_max(p0, p8), __builtin_elementwise_max(p4, p12));
+    const us2_t lo = __builtin_elementwise_max(__builtin_elementwise_min(p0, p8), __builtin_elementwise_min(p4, p12));
+    return __builtin_elementwise_max(__builtin_elementwise_sub_sat(hi, v), __builtin_elementwise_sub_sat(v, lo));
+}
+
 constexpr int kFastTileFixed = 48, kFastScoreFixed = 40;   // pitches of the specialised wave-per-cell kernel
 
 // ---------------------------------------------------------------------------
@@ -395,35 +430,17 @@ constexpr int kFastTileFixed = 48, kFastScoreFixed = 40;   // pitches of the spe
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // TPC / SPC: compile-time tile and score pitches (0 = take them from fl): with constants every
 // ring pixel is an immediate offset from one LDS address.
-template <int TPC = 0, int SPC = 0>
-__global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
-                                                        uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
-                                                        const FastCell* __restrict__ cells, int frame_per_xcd, unsigned long long rcp_ncells, int nframes)
+template <int TPC, int SPC>
+__device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, const FrameGeom& g, const FastLds& fl,
+                                              uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
+                                              const FastCell* __restrict__ cells, int cell, int f, unsigned char* smem)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    // one wavefront = one workgroup = one cell: wave-level fences replace workgroup barriers
+    // one wavefront = one workgroup: wave-level fences replace workgroup barriers
     uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);
     uint8_t* s_score = smem + fl.score_off;
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(smem + fl.queue_off);
     const int TP = TPC ? TPC : fl.tile_pitch, SP = SPC ? SPC : fl.score_pitch;
-
     const int lane = threadIdx.x;
-    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Neighbouring
-    // tiles share their 3-pixel rings and cache lines, so a large batch gives every frame to one
-    // XCD (1-D grid, block b -> XCD b % 8 -> frame 8 * (b / 8 / ncells) + b % 8): 2.8x less
-    // fetch than cells scattered over all L2s.  Small batches use the plain (cell, frame) grid
-    // so that one frame still spreads over the whole device.
-    int cell, f;
-    if (frame_per_xcd) {
-        const uint32_t seq = blockIdx.x >> 3;
-        const uint32_t fq = (uint32_t)(((unsigned long long)seq * rcp_ncells) >> 40);    // seq / ncells
-        cell = (int)(seq - fq * (uint32_t)g.ncells);
-        f = (int)(fq * 8 + (blockIdx.x & 7));
-        if (f >= nframes) return;
-    } else {
-        cell = blockIdx.x;
-        f = blockIdx.y;
-    }
     const FastCell fc = cells[cell];                 // wave-uniform: one scalar load
     const int cw = fc.cw, ch = fc.ch, ox = fc.ox, ndw = fc.ndw, pitch = fc.pitch, cell_cap = fc.cell_cap;
     int* count_out = cell_count + (size_t)f * g.ncells + cell;
@@ -447,95 +464,141 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
     const int npix = cw * ch;
     const uint32_t rcp_cw = fc.rcp_cw;                           // i / cw for i < 2^12, cw <= 64
-    const int t = g.minTh;
+    const int t = g.minTh, ts = max(g.iniTh, t);
     int nq = 0;
     // The queue holds qcap entries, enough for any natural image; when a round might not fit
     // (noise: most pixels pass), the queued pixels are scored at once and the queue restarts.
     // `flushed` then sends the maxima search over all pixels instead of over the queue.
+    // Queue entry: pixel index (12 bits) | 0x8000 if the pretest value exceeds iniThFAST as well.
     const int qcap = fl.queue_cap;
     bool flushed = false;
-    auto score_queue = [&]() {
-        WAVE_SYNC();
-        for (int q0 = 0; q0 < nq; q0 += 64) {
+    auto score_entries = [&](int lo, int hi) {
+        for (int q0 = lo; q0 < hi; q0 += 64) {
             const int q = q0 + lane;
-            if (q < nq) {
-                const int i = s_queue[q];
+            if (q < hi) {
+                const int i = s_queue[q] & 0x0fff;
                 const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
                 const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
                 s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
             }
         }
+    };
+    auto score_queue = [&]() {
+        WAVE_SYNC();
+        score_entries(0, nq);
         WAVE_SYNC();
     };
-    const int TP3 = 3 * TP;
-    if (fc.rpr) {
-        // whole rows per round: lane = (row r of the round, column c); a round advances every lane
-        // by rpr rows, i.e. by constants.  Lanes past rpr * cw idle (at most 12 of 64).
-        const int R = fc.rpr;
-        const int r = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18), c = lane - __mul24(r, cw);
-        const int step_addr = R * TP, step_idx = R * cw;
-        int addr = __mul24(r + 3, TP) + c + 3 + ox;
-        int idx = r < R ? lane : npix;               // pixel index row * cw + c; idle lanes never pass the bound
-        // two rounds per iteration: their ten LDS reads are in flight together and the loop
-        // bookkeeping is paid once
-        for (int y0 = 0; y0 < ch; y0 += 2 * R) {
-            if (nq + 128 > qcap) { score_queue(); nq = 0; flushed = true; }
-            const int idx2 = idx + step_idx;
-            bool pass = false, pass2 = false;
-            {
-                const uint8_t* p = tile8 + addr;
-                const uint8_t* p2 = p + step_addr;
-                // rows past the cell still lie inside the LDS block (the score tile follows): read, then discard
-                const int v = p[0], p0 = p[TP3], p4 = p[3], p8 = p[-TP3], p12 = p[-3];
-                const int w = p2[0], q0 = p2[TP3], q4 = p2[3], q8 = p2[-TP3], q12 = p2[-3];
-                const int br = min(max(p0, p8), max(p4, p12)) - v;
-                const int dk = v - max(min(p0, p8), min(p4, p12));
-                const int br2 = min(max(q0, q8), max(q4, q12)) - w;
-                const int dk2 = w - max(min(q0, q8), min(q4, q12));
-                pass = max(br, dk) > t && idx < npix;
-                pass2 = max(br2, dk2) > t && idx2 < npix;
-            }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            const unsigned long long bal = __ballot(pass), bal2 = __ballot(pass2);
-            if (pass) s_queue[nq + __popcll(bal & below)] = (uint16_t)idx;
-            nq += __popcll(bal);
-            if (pass2) s_queue[nq + __popcll(bal2 & below)] = (uint16_t)idx2;
-            nq += __popcll(bal2);
-            addr += 2 * step_addr;
-            idx += 2 * step_idx;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    {
+        // Pretest, four horizontally adjacent pixels per lane: lane = (row r of the round, group c of
+        // 4 columns), lpr = ceil(cw / 4) lanes per row, R = 64 / lpr rows per round.  Five dword reads
+        // (rows y-3 and y+3 at x, row y at x-3, x, x+3) feed packed 16-bit arithmetic; the survivors of
+        // a round are counted per lane, placed by a wave scan and written in pixel order.
+        const int lpr = fc.lpr, R = fc.fast_rows;
+        const int r = (int)(__umul24((uint32_t)lane, fc.rcp_lpr) >> 16), c = lane - __mul24(r, lpr), c4 = 4 * c;
+        // Misaligned LDS dwords are slow, so each of the five is cut out of an aligned pair: the
+        // byte offsets (ox, ox + 3, ox + 6 from the lane's aligned column group) are wave-uniform.
+        const int TPW = TP >> 2, TPW3 = 3 * TPW;
+        const int jv = ox + 3, j4 = ox + 6;
+        int w0 = __mul24(r, TPW) + c;                      // dword index of row y-3 at the lane's column group
+        int row = r < R ? r : ch;                           // lanes past the last whole row never become valid
+        const uint32_t i0 = (uint32_t)(__mul24(r, cw) + c4);
+        uint32_t idxE = i0 | ((i0 + 2) << 16), idxO = (i0 + 1) | ((i0 + 3) << 16);
+        const uint32_t stepi = (uint32_t)__mul24(R, cw), step2 = stepi | (stepi << 16);
+        const int nv = cw - c4;                             // valid pixels of this lane's group: columns < cw
+        const uint32_t colE = (nv > 0 ? 0x0000ffffu : 0u) | (nv > 2 ? 0xffff0000u : 0u);
+        const uint32_t colO = (nv > 1 ? 0x0000ffffu : 0u) | (nv > 3 ? 0xffff0000u : 0u);
+        const us2_t t2 = {(unsigned short)t, (unsigned short)t}, ts2 = {(unsigned short)ts, (unsigned short)ts};
+        const uint32_t one2 = 0x00010001u;
+        const int step_w = __mul24(R, TPW);
+        for (int y0 = 0; y0 < ch; y0 += R) {
+            if (nq + 256 > qcap) { score_queue(); nq = 0; flushed = true; }
+            // rows past the cell still lie inside the LDS block (the score tile follows): read, then discard
+            const uint32_t* qa = s_tile + w0;
+            const uint32_t* qv = qa + (jv >> 2);
+            const uint32_t* q4 = qa + (j4 >> 2);
+            const uint32_t a8 = __builtin_amdgcn_alignbyte(qv[1], qv[0], jv & 3);
+            const uint32_t av = __builtin_amdgcn_alignbyte(qv[TPW3 + 1], qv[TPW3], jv & 3);
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(qv[2 * TPW3 + 1], qv[2 * TPW3], jv & 3);
+            const uint32_t a12 = __builtin_amdgcn_alignbyte(qa[TPW3 + 1], qa[TPW3], ox);
+            const uint32_t a4 = __builtin_amdgcn_alignbyte(q4[TPW3 + 1], q4[TPW3], j4 & 3);
+            const us2_t mE = compass2(even_bytes(av), even_bytes(a0), even_bytes(a8), even_bytes(a4), even_bytes(a12));
+            const us2_t mO = compass2(odd_bytes(av), odd_bytes(a0), odd_bytes(a8), odd_bytes(a4), odd_bytes(a12));
+            const bool row_ok = row < ch;
+            const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, t2)) & (row_ok ? colE : 0u);
+            const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, t2)) & (row_ok ? colO : 0u);
+            const us2_t cE = pk_min_u16(__builtin_bit_cast(us2_t, dE), one2);          // 1 per survivor
+            const us2_t cO = pk_min_u16(__builtin_bit_cast(us2_t, dO), one2);
+            const us2_t sE = pk_min_u16(__builtin_elementwise_sub_sat(mE, ts2), one2) << (unsigned short)15;
+            const us2_t sO = pk_min_u16(__builtin_elementwise_sub_sat(mO, ts2), one2) << (unsigned short)15;
+            const us2_t eE = __builtin_bit_cast(us2_t, idxE) + sE, eO = __builtin_bit_cast(us2_t, idxO) + sO;
+            const uint32_t both = __builtin_bit_cast(uint32_t, cE) + __builtin_bit_cast(uint32_t, cO);
+            const int cnt = (int)((both & 0xffffu) + (both >> 16));
+            const int incl = wave_incl_scan(cnt);
+            int pos = nq + incl - cnt;
+            if (cE.x) s_queue[pos] = eE.x;
+            pos += cE.x;
+            if (cO.x) s_queue[pos] = eO.x;
+            pos += cO.x;
+            if (cE.y) s_queue[pos] = eE.y;
+            pos += cE.y;
+            if (cO.y) s_queue[pos] = eO.y;
+            nq += __builtin_amdgcn_readlane(incl, 63);
+            w0 += step_w;
+            row += R;
+            idxE += step2;
+            idxO += step2;
         }
-    } else {
-        // the lane's pixel advances by 64 positions per round: keep its column and tile offset
-        // incrementally instead of dividing every round
-        const int q64 = (int)(__umul24(64u, rcp_cw) >> 18), r64 = 64 - q64 * cw;     // 64 = q64*cw + r64
-        const int adv = q64 * TP + r64, wrap = TP - cw;
-        int px;
-        int addr;
-        {
-            const int py0 = (int)(__umul24((uint32_t)lane, rcp_cw) >> 18);
-            px = lane - __mul24(py0, cw);
-            addr = __mul24(py0 + 3, TP) + px + 3 + ox;
+    }
+    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
+    int base = 0;
+    if (!flushed) {
+        // Only pixels whose pretest value exceeds iniThFAST (the score is below the pretest value) can be
+        // corners of the reference's first cv::FAST call, and a neighbour that is not among them cannot
+        // out-score one that is.  They are copied, in order, behind the queue, scored, and their strict
+        // maxima at iniThFAST emitted: when there is at least one, that is the cell's result and the
+        // other survivors (natural images: 2/3 of them) are never scored.
+        int ns = 0;
+        WAVE_SYNC();
+        for (int q0 = 0; q0 < nq; q0 += 64) {
+            const int q = q0 + lane;
+            const int e = q < nq ? s_queue[q] : 0;
+            const bool strong = (e & 0x8000) != 0;
+            const unsigned long long bal = __ballot(strong);
+            const int pos = nq + ns + __popcll(bal & below);
+            if (strong && pos < qcap) s_queue[pos] = (uint16_t)e;
+            ns += __popcll(bal);
         }
-        for (int i0 = 0; i0 < npix; i0 += 64) {
-            if (nq + 64 > qcap) { score_queue(); nq = 0; flushed = true; }
-            const int i = i0 + lane;
-            bool pass = false;
-            if (i < npix) {
-                const uint8_t* c = tile8 + addr;
-                // two adjacent compass points brighter than v + t  <=>  min(max(p0,p8), max(p4,p12)) - v > t
-                // (every pair of one vertical and one horizontal compass point is adjacent); likewise darker
-                const int v = c[0];
-                const int p0 = c[TP3], p4 = c[3], p8 = c[-TP3], p12 = c[-3];
-                const int br = min(max(p0, p8), max(p4, p12)) - v;
-                const int dk = v - max(min(p0, p8), min(p4, p12));
-                pass = max(br, dk) > t;
+        if (ns > 0 && nq + ns <= qcap) {
+            WAVE_SYNC();
+            score_entries(nq, nq + ns);
+            WAVE_SYNC();
+            for (int q0 = nq; q0 < nq + ns; q0 += 64) {
+                const int q = q0 + lane;
+                bool hit = false;
+                int py = 0, px = 0, s = 0;
+                if (q < nq + ns) {
+                    const int i = s_queue[q] & 0x0fff;
+                    py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
+                    px = i - __mul24(py, cw);
+                    const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
+                    s = sc[0];
+                    const int m0 = max(max((int)sc[-SP - 1], (int)sc[-SP]), (int)sc[-SP + 1]);
+                    const int m1 = max(max((int)sc[SP - 1], (int)sc[SP]), (int)sc[SP + 1]);
+                    const int m2 = max(max((int)sc[-1], (int)sc[1]), 0);
+                    hit = s > max(max(m0, m1), m2) && s >= g.iniTh;
+                }
+                const unsigned long long bal = __ballot(hit);
+                if (hit) {
+                    const int pos = base + __popcll(bal & below);
+                    if (pos < cell_cap) out[pos] = ((uint32_t)py << 16) | ((uint32_t)px << 8) | (uint32_t)s;
+                }
+                base += __popcll(bal);
             }
-            px += r64;
-            addr += adv;
-            if (px >= cw) { px -= cw; addr += wrap; }
-            const unsigned long long bal = __ballot(pass);
-            if (pass) s_queue[nq + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)i;
-            nq += __popcll(bal);
+            if (base > 0) {
+                if (lane == 0) *count_out = min(base, cell_cap);
+                return;
+            }
         }
     }
     score_queue();
@@ -543,8 +606,6 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     // here, in queue (= row-major) order: if the cell has any, they are its whole result
     // (the first cv::FAST call of the reference found something).  Only a cell without one
     // needs the second sweep, which emits every flagged maximum (the minThFAST call).
-    uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
-    int base = 0;
     if (flushed) {
         // rare path: the queue no longer lists every candidate, so visit every pixel (row-major);
         // first for maxima at the initial threshold, then, if there is none, for all maxima
@@ -579,7 +640,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         bool hit = false;
         int py = 0, px = 0, s = 0;
         if (q < nq) {
-            const int i = s_queue[q];
+            const int i = s_queue[q] & 0x0fff;
             py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
             px = i - __mul24(py, cw);
             const uint8_t* sc = s_score + (py + 1) * SP + px + 1;
@@ -588,7 +649,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             const int m1 = max(max((int)sc[SP - 1], (int)sc[SP]), (int)sc[SP + 1]);
             const int m2 = max(max((int)sc[-1], (int)sc[1]), 0);
             if (s > max(max(m0, m1), m2)) {            // strict maximum of its 8 neighbours, and non-zero
-                s_queue[q] = (uint16_t)(i | 0x8000);
+                s_queue[q] = (uint16_t)(i | 0x4000);
                 hit = s >= g.iniTh;
             }
         }
@@ -607,8 +668,8 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
             int py = 0, px = 0, s = 0;
             if (q < nq) {
                 const int e = s_queue[q];
-                if (e & 0x8000) {
-                    const int i = e & 0x7fff;
+                if (e & 0x4000) {
+                    const int i = e & 0x0fff;
                     py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18);
                     px = i - __mul24(py, cw);
                     s = s_score[(py + 1) * SP + px + 1];
@@ -626,25 +687,42 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
     if (lane == 0) *count_out = min(base, cell_cap);
 }
 
+// One wavefront = one workgroup = one cell.  (Several cells per wavefront to save workgroup dispatches
+// measured slower: the dispatch of one cell overlaps the arithmetic of the others.)
+// One wavefront = one workgroup = one cell.  (Several cells per wavefront, or several one-cell
+// wavefronts per workgroup, measured slower: the kernel is bound by vector instruction issue, and
+// the dispatch and tile load of one cell overlap the arithmetic of the others.)
+template <int TPC = 0, int SPC = 0>
+__global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
+                                                        uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
+                                                        const FastCell* __restrict__ cells, int frame_per_xcd,
+                                                        unsigned long long rcp_ncells, int nframes)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Neighbouring
+    // tiles share their 3-pixel rings and cache lines, so a large batch gives every frame to one
+    // XCD (1-D grid, block b -> XCD b % 8 -> frame 8 * (b / 8 / ncells) + b % 8): 2.8x less
+    // fetch than cells scattered over all L2s.  Small batches use the plain (cell, frame) grid
+    // so that one frame still spreads over the whole device.
+    int cell, f;
+    if (frame_per_xcd) {
+        const uint32_t seq = blockIdx.x >> 3;
+        const uint32_t fq = (uint32_t)(((unsigned long long)seq * rcp_ncells) >> 40);    // seq / ncells
+        cell = (int)(seq - fq * (uint32_t)g.ncells);
+        f = (int)(fq * 8 + (blockIdx.x & 7));
+        if (f >= nframes) return;
+    } else {
+        cell = blockIdx.x;
+        f = blockIdx.y;
+    }
+    fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, cell, f, smem);
+}
+
 #undef WAVE_SYNC
 
 // ---------------------------------------------------------------------------
 // block-wide scans (NT threads = NT / 64 wavefronts per workgroup)
 // ---------------------------------------------------------------------------
-// inclusive scan over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside each row of
-// 16 lanes (row_shr 1, 2, 4, 8 shifting zeros in), then the last lane of rows 0 and 2 is added to
-// rows 1 and 3 (row_bcast15), then lane 31 to rows 2 and 3 (row_bcast31)
-__device__ __forceinline__ int wave_incl_scan(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast15 into rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast31 into rows 2, 3
-    return v;
-}
-
 // exclusive scan of one value per thread; tmp = NT / 64 ints of LDS
 template <int NT>
 __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
@@ -1065,7 +1143,8 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
     // a queue for 640 pretest survivors (natural images: about 200 of a cell's ~1000 pixels) instead of one
     // for every pixel keeps a wavefront's LDS under 5 KB, i.e. 8 wavefronts per SIMD
-    fl.queue_cap = std::min((wc * hc + 63) & ~63, getenv("ORBX_FAST_QCAP") ? atoi(getenv("ORBX_FAST_QCAP")) : 640);
+    // (never below 256: one pretest round can queue four pixels per lane)
+    fl.queue_cap = std::max(256, std::min((wc * hc + 63) & ~63, getenv("ORBX_FAST_QCAP") ? atoi(getenv("ORBX_FAST_QCAP")) : 640));
     fl.total = fl.queue_off + 2 * fl.queue_cap + 16;
     fl.total = (fl.total + 15) & ~15;
 }

@@ -248,8 +248,11 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
             fc.ch = (uint8_t)ch;
             fc.ox = (uint8_t)ox;
             fc.ndw = (uint8_t)ndw;
-            // rows per pretest round; worth it while at least 52 of the 64 lanes stay busy
-            fc.rpr = (uint8_t)(((64 / cw) * cw >= 52) ? 64 / cw : 0);
+            // pretest lane layout: four pixels per lane, whole rows per 64-lane round
+            const int lpr = (cw + 3) / 4;
+            fc.lpr = (uint8_t)lpr;
+            fc.fast_rows = (uint8_t)(64 / lpr);
+            fc.rcp_lpr = (uint32_t)((65536 + lpr - 1) / lpr);
         }
     }
     g.pyr_frame_bytes = (uint32_t)pyr;

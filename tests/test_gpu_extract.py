@@ -87,6 +87,19 @@ def test_batch_equals_single(gpu, oracle):
         assert np.array_equal(res[i][1], desc_o)
 
 
+def test_large_batch_shapes(gpu, oracle, euroc_left):
+    """From 32 frames on every frame's FAST cells and keypoints stay on one XCD and the quadtree runs
+    in its batch shape: 40 frames (natural, synthetic and noise) against the oracle."""
+    imgs = synthetic_batch(40, 752, 480, seed0=4400)
+    imgs[7] = euroc_left
+    imgs[33] = np.random.default_rng(8).integers(0, 256, size=(480, 752), dtype=np.uint8)
+    res = gpu.extract_batch(imgs)
+    for i in (0, 7, 15, 33, 39):
+        kps_o, desc_o = _compare_frame(gpu, oracle, imgs[i], frame=i, check_stages=(i in (7, 33)))
+        _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+        assert np.array_equal(res[i][1], desc_o)
+
+
 def test_degenerate_frames(gpu, oracle):
     # constant image: no keypoints, descriptors released
     k, d = gpu(np.full((480, 752), 77, np.uint8))
@@ -129,10 +142,11 @@ def test_quadtree_batch_shape_on_small_batch(gpu, oracle, monkeypatch):
 
 def test_fast_queue_overflow_path(oracle, monkeypatch):
     """The per-cell FAST kernel queues pretest survivors in a bounded LDS queue and falls back to
-    a dense maxima search when a cell overflows it (noise).  Force the fallback everywhere with a
-    64-entry queue and require identical results, stage by stage."""
+    a dense maxima search when a cell overflows it (noise).  Force the fallback with the smallest
+    queue (256 entries: every cell of the noise image and the busy cells of the synthetic one
+    overflow it) and require identical results, stage by stage."""
     from orb_slam_amd import ORBextractor
-    monkeypatch.setenv("ORBX_FAST_QCAP", "64")
+    monkeypatch.setenv("ORBX_FAST_QCAP", "256")
     ex = ORBextractor(1000, 1.2, 8, 20, 7)
     for img in (synthetic_frame(752, 480, 4242),
                 np.random.default_rng(6).integers(0, 256, size=(480, 752), dtype=np.uint8)):

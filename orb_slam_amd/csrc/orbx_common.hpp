@@ -24,6 +24,7 @@ struct LevelGeom {
     // detection region [16, w-16) x [16, h-16) and its cell grid (src/ORBextractor.cc:1036-1050)
     int width, height;     // region size; 0 if the level is too small to be searched
     int nCols, nRows, wCell, hCell;
+    uint32_t rcp_ncols;    // ceil(2^32 / nCols) for nCols > 1: cell / nCols = umulhi(cell, rcp_ncols)
     int cell_base;         // index of this level's first cell in the per-frame cell array
     int cell_cap;          // candidate slots per cell
     uint32_t cand_base;    // first candidate slot of this level inside one frame (cells * cell_cap)

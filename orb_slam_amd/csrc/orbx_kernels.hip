@@ -154,8 +154,11 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
     // into many cache accesses, so fetch the 3 aligned dwords around them and shift (row offsets,
     // plane offsets and pitches are multiples of 4: the misalignment is the lane's constant).
     const uint32_t shx = x.base & 3u;
-    const uint8_t* src = frame + P.plane_off + (x.base & ~3u);
-    uint8_t* dst = frame + L.plane_off + 4 * dwc;
+    // addresses = wave-uniform row pointer + the lane's 32-bit offset: the form a global load / store
+    // takes as scalar base + vector offset, with no 64-bit vector arithmetic per access
+    const uint8_t* src = frame + P.plane_off;
+    uint8_t* dst = frame + L.plane_off;
+    const uint32_t xoff = x.base & ~3u, doff = 4u * (uint32_t)dwc;
     const YTab2* yt = ytab + L.ytab2_off;
     const int rlast = L.rows - 1;
     // Groups of 4 rows, all loads issued before the arithmetic; a group that runs past the plane
@@ -178,8 +181,8 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (fresh[k]) t0[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off0);
-            t1[k] = *reinterpret_cast<const Aligned12*>(src + y[k].off1);
+            if (fresh[k]) t0[k] = *reinterpret_cast<const Aligned12*>(src + (size_t)(uint32_t)(y[k].off0 + xoff));
+            t1[k] = *reinterpret_cast<const Aligned12*>(src + (size_t)(uint32_t)(y[k].off1 + xoff));
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -208,7 +211,7 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
                 o |= (v & 0xffu) << (8 * j);
                 hp[j] = h1[j];
             }
-            *reinterpret_cast<uint32_t*>(dst + (size_t)rr[k] * L.pitch) = o;
+            *reinterpret_cast<uint32_t*>(dst + (size_t)((uint32_t)(rr[k] * (int)L.pitch) + doff)) = o;
         }
         prev_off = y[3].off1;
     }
@@ -290,9 +293,13 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     const int dw = flat - rb * ndw;                      // dword column inside the level image
     const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
     const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
-    const uint8_t* src = pyr + fbase + (size_t)(kPadY + y0 - 3) * L.pitch + kPadX + 4 * dw - 4;
-    uint8_t* dst = blur + fbase + (size_t)(kPadY + y0) * L.pitch + kPadX + 4 * dw;
-    const int pitch = L.pitch;
+    // addresses = wave-uniform plane pointer + the lane's 32-bit offset (scalar base + vector offset
+    // in the load / store, one 32-bit add per row instead of 64-bit vector arithmetic)
+    const uint8_t* src = pyr + fbase;
+    uint8_t* dst = blur + fbase;
+    const uint32_t pitch = (uint32_t)L.pitch;
+    const uint32_t soff = __umul24((uint32_t)(kPadY + y0 - 3), pitch) + (uint32_t)(kPadX + 4 * dw - 4);
+    const uint32_t doff = __umul24((uint32_t)(kPadY + y0), pitch) + (uint32_t)(kPadX + 4 * dw);
 
     // Branch-free schedule: 6 warm-up rows, then groups of 6 rows whose loads are all issued
     // before the arithmetic.  A band's last group may run past the band (at most 5 rows): those
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
 #pragma unroll
     for (int p = 0; p < 6; p++) {
         uint32_t hc[4];
-        blur_hsum4(src + (size_t)p * pitch, hc);
+        blur_hsum4(src + (size_t)(soff + __umul24((uint32_t)p, pitch)), hc);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (p > 0) P[p][j] = hprev[j] | (hc[j] << 16);
@@ -315,12 +322,11 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     }
     const int nrows = y1 - y0;
     for (int r0 = 0; r0 < nrows; r0 += 6) {
-        const uint8_t* sp = src + (size_t)(r0 + 6) * pitch;
-        uint8_t* dp = dst + (size_t)r0 * pitch;
+        const uint32_t so = soff + __umul24((uint32_t)(r0 + 6), pitch), dofs = doff + __umul24((uint32_t)r0, pitch);   // rows, pitch < 2^24
         uint32_t raw[6][3];
 #pragma unroll
         for (int p = 0; p < 6; p++) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(sp + (size_t)p * pitch);
+            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)(so + __umul24((uint32_t)p, pitch)));
             raw[p][0] = q[0]; raw[p][1] = q[1]; raw[p][2] = q[2];
         }
 #pragma unroll
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
             }
             const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
             const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
-            *reinterpret_cast<uint32_t*>(dp + (size_t)p * pitch) = lo | (hi << 16);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(dofs + __umul24((uint32_t)p, pitch))) = lo | (hi << 16);
         }
     }
 }
@@ -452,8 +458,8 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     const int th = ch + 6;
     const uint32_t rcp_ndw = fc.rcp_ndw;                        // i / ndw for i < 2^12, ndw <= 20
     for (int i = lane; i < th * ndw; i += 64) {
-        int r = (int)(((uint32_t)i * rcp_ndw) >> 16), c = i - r * ndw;
-        s_tile[r * (TP >> 2) + c] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(r * pitch + 4 * c));
+        int r = (int)(__umul24((uint32_t)i, rcp_ndw) >> 16), c = i - __mul24(r, ndw);
+        s_tile[r * (TP >> 2) + c] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(r, pitch) + 4 * c));
     }
     {
         uint32_t* sc32 = reinterpret_cast<uint32_t*>(s_score);
@@ -873,10 +879,11 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         }
         const int c = lo;
         const int o = off_in_lds ? s_off[c] : coff[c];
-        const uint32_t u = cands[(size_t)c * L.cell_cap + (i - o)];
-        const int ci = c / L.nCols, cj = c - ci * L.nCols;
-        const int x = cj * L.wCell + 3 + (int)((u >> 8) & 0xff);
-        const int y = ci * L.hCell + 3 + (int)(u >> 16);
+        // small operands: 24-bit multiplies and a reciprocal instead of 32-bit multiplies and a division
+        const uint32_t u = cands[(uint32_t)(__mul24(c, L.cell_cap) + (i - o))];
+        const int ci = L.nCols > 1 ? (int)__umulhi((uint32_t)c, L.rcp_ncols) : c, cj = c - __mul24(ci, L.nCols);
+        const int x = __mul24(cj, L.wCell) + 3 + (int)((u >> 8) & 0xff);
+        const int y = __mul24(ci, L.hCell) + 3 + (int)(u >> 16);
         xy = (uint32_t)x | ((uint32_t)y << 16);
         resp = u & 0xff;
         kxy[i] = xy;
@@ -1299,12 +1306,19 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     const uint8_t* bf = blur + (size_t)f * g.pyr_frame_bytes;
     const int sh = (kPadX + x - kDescRadius) & 3;            // bytes between the aligned window start and column x-18
     const int win0 = ctr - kDescRadius * pitch - kDescRadius - sh;
-    uint32_t wv[(kWinItems + 31) / 32];
+    // 16 lanes per window row (10 of them load), two rows per step: more loads than a dense 32-lane
+    // packing, but every address is the previous one plus two pitches
+    constexpr int kWinSteps = (kWinRows + 1) / 2;
+    const int wrow = lane >> 4, wq = lane & 15;
+    uint32_t wv[kWinSteps];
+    {
+        uint32_t wo = (uint32_t)(win0 + __mul24(wrow, pitch) + 4 * min(wq, kWinDw - 1));
 #pragma unroll
-    for (int t = 0; t < (kWinItems + 31) / 32; t++) {
-        const int i = min(lane + 32 * t, kWinItems - 1);
-        const int r = (i * 6554) >> 16, q = i - r * kWinDw;   // i / 10 for i < 16384
-        wv[t] = *reinterpret_cast<const uint32_t*>(bf + (uint32_t)(win0 + r * pitch + 4 * q));
+        for (int t = 0; t < kWinSteps; t++) {
+            // the row after the last one (odd row count) is read like any other and dropped at the store
+            wv[t] = *reinterpret_cast<const uint32_t*>(bf + wo);
+            wo += 2u * (uint32_t)pitch;
+        }
     }
 
     // IC_Angle :74-101 on the un-blurred level: lane = patch column u = lane-15, walking the
@@ -1336,9 +1350,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     const float angle = fast_atan2_deg((float)m01, (float)m10);
 
     uint32_t* win = s_win[tid >> 5];
+    if (wq < kWinDw) {
 #pragma unroll
-    for (int t = 0; t < (kWinItems + 31) / 32; t++)
-        if (lane + 32 * t < kWinItems) win[lane + 32 * t] = wv[t];
+        for (int t = 0; t < kWinSteps; t++)
+            if (2 * t + 1 < kWinRows || wrow == 0) win[(2 * t + wrow) * kWinDw + wq] = wv[t];
+    }
     WAVE_SYNC();
 
     // computeOrbDescriptor :104-150 on the blurred level; lane = descriptor byte
@@ -1348,16 +1364,24 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     sincos_turn((double)rad, &sn, &cs);
     const float a = (float)cs, b = (float)sn;
     const uint8_t* win8 = reinterpret_cast<const uint8_t*>(win) + kDescRadius * (4 * kWinDw) + kDescRadius + sh;
+    // Rotation and rounding of a test point: (row, col) = (x b + y a, x a - y b), every product and
+    // sum rounded on its own as in the reference (the compiler pairs them into two-float
+    // instructions), then cvRound by adding 1.5 * 2^23, which leaves
+    // 0x4B400000 + round-half-even(value) in the bits.  The window offset row * 40 + col comes
+    // straight from those bits: a 24-bit multiply sees 0x400000 + row, the rest is one constant.
+    constexpr uint32_t kUnbias = 0x400000u * (uint32_t)(4 * kWinDw) + 0x4B400000u;
+    auto sample = [&](float px, float py) -> int {
+        const float rr = __fadd_rn(__fadd_rn(__fmul_rn(px, b), __fmul_rn(py, a)), 12582912.f);
+        const float cc = __fadd_rn(__fsub_rn(__fmul_rn(px, a), __fmul_rn(py, b)), 12582912.f);
+        const uint32_t off = (uint32_t)__umul24(__builtin_bit_cast(uint32_t, rr), (uint32_t)(4 * kWinDw)) + __builtin_bit_cast(uint32_t, cc) - kUnbias;
+        return win8[(int)off];
+    };
     int val = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float4 pt = s_pat[j * 32 + lane];
-        const int r0 = round_rn(__fadd_rn(__fmul_rn(pt.x, b), __fmul_rn(pt.y, a)));
-        const int c0 = round_rn(__fsub_rn(__fmul_rn(pt.x, a), __fmul_rn(pt.y, b)));
-        const int r1 = round_rn(__fadd_rn(__fmul_rn(pt.z, b), __fmul_rn(pt.w, a)));
-        const int c1 = round_rn(__fsub_rn(__fmul_rn(pt.z, a), __fmul_rn(pt.w, b)));
-        const int t0 = win8[r0 * (4 * kWinDw) + c0];
-        const int t1 = win8[r1 * (4 * kWinDw) + c1];
+        const int t0 = sample(pt.x, pt.y);
+        const int t1 = sample(pt.z, pt.w);
         val |= (t0 < t1) << j;
     }
     out_desc[((size_t)f * cap + oi) * 32 + lane] = (uint8_t)val;

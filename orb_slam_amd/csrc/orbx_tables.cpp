@@ -155,6 +155,7 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
             L.height = height;
             L.nCols = (int)((float)width / W);
             L.nRows = (int)((float)height / W);
+            L.rcp_ncols = L.nCols > 1 ? (uint32_t)(((1ull << 32) + L.nCols - 1) / L.nCols) : 0u;
             L.wCell = (int)std::ceil((float)width / L.nCols);
             L.hCell = (int)std::ceil((float)height / L.nRows);
             if (L.wCell > 64 || L.hCell > 64) { *msg = "FAST cell larger than 64 pixels"; return ORBX_ERR_UNSUPPORTED; }

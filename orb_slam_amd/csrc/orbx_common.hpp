@@ -74,7 +74,7 @@ struct FastCell {
     uint32_t src_off;    // byte offset inside a frame of the tile's first dword (3-pixel ring included)
     uint32_t cand_off;   // first candidate slot of this cell inside a frame
     uint32_t rcp_cw;     // ceil(2^18 / cw): i / cw for i < 2^12
-    uint32_t rcp_ndw;    // ceil(2^16 / ndw): i / ndw for i < 2^12
+    uint32_t pad32;
     uint16_t pitch;      // plane pitch
     uint16_t cell_cap;   // candidate slots
     uint8_t cw, ch;      // tested area (0: empty cell)

@@ -456,14 +456,27 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     }
     const uint8_t* src = pyr + (size_t)f * g.pyr_frame_bytes + fc.src_off;
     const int th = ch + 6;
-    const uint32_t rcp_ndw = fc.rcp_ndw;                        // i / ndw for i < 2^12, ndw <= 20
-    for (int i = lane; i < th * ndw; i += 64) {
-        int r = (int)(__umul24((uint32_t)i, rcp_ndw) >> 16), c = i - __mul24(r, ndw);
-        s_tile[r * (TP >> 2) + c] = *reinterpret_cast<const uint32_t*>(src + (uint32_t)(__mul24(r, pitch) + 4 * c));
+    // Tile load: 16 lanes per tile row (32 when the pitch is not the compiled-in one), whole rows per
+    // step, so that every address is the previous one plus a constant.  A denser packing of the
+    // lanes needs fewer loads but a division per dword, and this kernel is bound by instruction issue.
+    {
+        constexpr int LPR = TPC ? 16 : 32, RPS = 64 / LPR;
+        const int rr = lane / LPR, cc = lane & (LPR - 1);
+        if (cc < ndw) {
+            uint32_t so = (uint32_t)(__mul24(rr, pitch) + 4 * cc);
+            uint32_t* d = s_tile + rr * (TP >> 2) + cc;
+            const uint32_t sstep = (uint32_t)(RPS * pitch);
+            for (int r = rr; r < th; r += RPS) {
+                *d = *reinterpret_cast<const uint32_t*>(src + (size_t)so);
+                so += sstep;
+                d += RPS * (TP >> 2);
+            }
+        }
     }
     {
-        uint32_t* sc32 = reinterpret_cast<uint32_t*>(s_score);
-        for (int i = lane; i < ((ch + 2) * SP) >> 2; i += 64) sc32[i] = 0;
+        // the score tile ends on a 16-byte boundary of its own (the queue starts at the next one)
+        uint4* sc128 = reinterpret_cast<uint4*>(s_score);
+        for (int i = lane; i < ((ch + 2) * SP + 15) >> 4; i += 64) sc128[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     WAVE_SYNC();
 

@@ -244,7 +244,6 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
             if (cw == 0 || ch == 0) continue;      // cw = ch = 0: the kernel only writes a zero count
             fc.src_off = L.plane_off + (uint32_t)prow0 * (uint32_t)L.pitch + (uint32_t)acol0;
             fc.rcp_cw = ((1u << 18) + cw - 1) / cw;
-            fc.rcp_ndw = (65536u + ndw - 1) / ndw;
             fc.cw = (uint8_t)cw;
             fc.ch = (uint8_t)ch;
             fc.ox = (uint8_t)ox;

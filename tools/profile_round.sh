@@ -1,7 +1,7 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box.  Usage (from the repo root):
 #   bash tools/profile_round.sh <tag>
-# Writes gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write}/...; tools/make_traffic.py turns the
+# Writes gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write,pmc_sq1,pmc_sq2,pmc_tcp}/... and the per-launch summaries; tools/make_traffic.py turns the
 # counter files into profiles/traffic.json.  Each profiler pass is its own short run.
 set -e -o pipefail
 TAG=${1:-r01}
@@ -13,4 +13,11 @@ cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_write.log 2>&1
-ls -R $OUT | head -40
+# issue / wait counters: at most 8 SQ and 4 TCP counters per pass
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_sq1.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_sq2 -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_sq2.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum --output-format csv -d $OUT/pmc_tcp -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_tcp.log 2>&1
+cd $ROOT
+python3 tools/pmc_summary.py $(find $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_tcp -name '*counter_collection.csv') > $OUT/pmc_sq_tcp_per_launch.txt
+python3 tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name '*counter_collection.csv') > $OUT/pmc_fetch_write_per_launch.txt
+ls -R $OUT | head -60

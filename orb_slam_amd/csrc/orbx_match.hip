@@ -165,8 +165,9 @@ __device__ __forceinline__ void mfma_sweep(const v4i_t* __restrict__ a_frag, con
             const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
 #pragma unroll
             for (int qt = 0; qt < kMfmaQT; qt++) {
-                // key = (|b| + 256 - 2 dot) << 22 | index
-                uint32_t key = (uint32_t)__mul24(acc[qt][4 * g + i], -8388608) + K[i];
+                // the queries are expanded to 0 / -1 bytes, so acc = -<a, b> and the key
+                // (|b| + 256 - 2 dot) << 22 | index is one shift-add
+                uint32_t key = ((uint32_t)acc[qt][4 * g + i] << 23) + K[i];
                 if (kPartial) key = ok ? key : 0xffffffffu;
                 push_key(best[qt], second[qt], key);
             }
@@ -204,6 +205,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_match_bruteforce_mfma(
 #pragma unroll
         for (int s = 0; s < 8; s++) {
             bq[qt][s] = expand16((qd[s] >> (16 * half)) & 0xffffu);
+            bq[qt][s] = (bq[qt][s] << 8) - bq[qt][s];          // 1 -> 0xff: the B operand holds 0 / -1
             pa[qt] += __popc(qd[s]);
         }
     }

@@ -1500,7 +1500,9 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
     // up to one workgroup per CU (32 frames x 8 levels) the wide shape is faster, beyond that the narrow one (measured)
-    static const int wide_max = getenv("ORBX_QT_WIDE_MAX") ? atoi(getenv("ORBX_QT_WIDE_MAX")) : 32;
+    // read per launch (a test switches it inside one process)
+    const char* e_wide = getenv("ORBX_QT_WIDE_MAX");
+    const int wide_max = e_wide ? atoi(e_wide) : 32;
     if (nframes <= wide_max)
         hipLaunchKernelGGL(k_quadtree_wide, grid, dim3(1024), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
                            key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);

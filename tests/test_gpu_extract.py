@@ -156,6 +156,22 @@ def test_fast_queue_overflow_path(oracle, monkeypatch):
     ex.close()
 
 
+def test_fast_variable_pitch_kernel(oracle, euroc_left, monkeypatch):
+    """Cells wider than 36 pixels run the FAST kernel with run-time LDS pitches instead of the
+    compiled-in ones.  Force that kernel on the usual geometry: identical results, stage by stage."""
+    from orb_slam_amd import ORBextractor
+    monkeypatch.setenv("ORBX_FAST_VAR_PITCH", "1")
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    try:
+        for img in (euroc_left, synthetic_frame(752, 480, 4343)):
+            kps_g, desc_g = ex(img)
+            kps_o, desc_o = _compare_frame(ex, oracle, img)
+            _assert_features(kps_g, desc_g, kps_o, desc_o)
+            assert np.array_equal(desc_g, desc_o)
+    finally:
+        ex.close()
+
+
 @pytest.mark.parametrize("cfg", [(1500, 1.5, 5, 25, 10), (800, 1.1, 8, 12, 5), (300, 2.0, 3, 20, 7), (1000, 1.2, 1, 20, 7)])
 def test_other_extractor_settings(cfg, euroc_left):
     """The constructor parameters of the reference's settings files vary (ORBextractor.nFeatures,

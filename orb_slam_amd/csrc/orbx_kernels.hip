@@ -781,6 +781,38 @@ __device__ __forceinline__ int lds_excl_scan(int* a, int n, int* tmp)
     return tot;
 }
 
+// two independent in-place exclusive scans sharing their barriers; tmp = 2 * NT / 64 ints
+template <int NT>
+__device__ __forceinline__ void lds_excl_scan2(int* a, int na, int* b, int nb, int* tmp, int* tot_a, int* tot_b)
+{
+    const int ca = (na + NT - 1) / NT, cb = (nb + NT - 1) / NT;
+    const int a0 = min((int)threadIdx.x * ca, na), a1 = min(a0 + ca, na);
+    const int b0 = min((int)threadIdx.x * cb, nb), b1 = min(b0 + cb, nb);
+    int sa = 0, sb = 0;
+    for (int i = a0; i < a1; i++) sa += a[i];
+    for (int i = b0; i < b1; i++) sb += b[i];
+    const int ia = wave_incl_scan(sa), ib = wave_incl_scan(sb);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 63) { tmp[w] = ia; tmp[NT / 64 + w] = ib; }
+    __syncthreads();
+    int base_a = 0, base_b = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        const int x = tmp[i], y = tmp[NT / 64 + i];
+        if (i < w) { base_a += x; base_b += y; }
+        ta += x;
+        tb += y;
+    }
+    *tot_a = ta;
+    *tot_b = tb;
+    base_a += ia - sa;
+    base_b += ib - sb;
+    for (int i = a0; i < a1; i++) { const int t = a[i]; a[i] = base_a; base_a += t; }
+    for (int i = b0; i < b1; i++) { const int t = b[i]; b[i] = base_b; base_b += t; }
+    __syncthreads();
+}
+
 // ---------------------------------------------------------------------------
 // DistributeOctTree (src/ORBextractor.cc:488-711) as array passes.
 //
@@ -801,7 +833,7 @@ struct QNode { short x0, x1, y0, y1; };
 __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
 {
     const size_t M = (size_t)M_;
-    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 32 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
+    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 64 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
 }
 constexpr int kKeyRegsWide = 3;   // register keys per thread of the 1024-thread shape (3072 keys per level)
 constexpr int kKeyRegs = 10;   // keys per thread held in registers (10 * 256 = 2560 keys per level); 91 VGPRs = 5 wavefronts per SIMD. 16 keys cost 210 VGPRs (2 per SIMD) and 40 % of the time
@@ -839,14 +871,14 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     int* s_B = s_A + M;                                                                 // M
     int* s_C = s_B + M;                                                                 // M
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                                 // M (only while ranking)
-    int* s_var = s_C + M;                                                               // 32
-    short* s_cidx = reinterpret_cast<short*>(s_var + 32);                               // 2*M
+    int* s_var = s_C + M;                                                               // 64
+    short* s_cidx = reinterpret_cast<short*>(s_var + 64);                               // 2*M
     unsigned short* s_childpos = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);     // 4*M
     unsigned short* s_newpos = s_childpos + 4 * M;                                      // M
     unsigned short* s_order = s_newpos + M;                                             // M
     unsigned short* s_cand = s_order + M;                                               // M
     unsigned char* s_fl = reinterpret_cast<unsigned char*>(s_cand + M);                 // M
-    int* s_tmp = s_var + 16;     // scan scratch, one int per wavefront
+    int* s_tmp = s_var + 16;     // scan scratch, one int per wavefront (two for the paired scan)
     // s_var[4]=size [5]=phase2 [6]=finish [7]=cntlt
 
     const int N = L.nfeat;
@@ -945,11 +977,22 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     const float hX = L.hX;
     for (int r = tid; r < nIni; r += NT) s_A[r] = 0;
     __syncthreads();
+    // every key adds to one of nIni (1 to 4) counters: count per wavefront with ballots and add once per
+    // wavefront and counter instead of queueing thousands of atomics on a handful of addresses
     FOR_KEYS({
         int x = (int)(xy & 0xffff);
         int r = (int)__fdiv_rn((float)x, hX);
         r = min(max(r, 0), nIni - 1);
-        atomicAdd(&s_A[r], 1);
+        if (nIni <= 4) {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);      // lanes that hold a key
+            const int leader = (int)__ffsll((long long)act) - 1;
+            for (int rr = 0; rr < nIni; rr++) {
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(r == rr);
+                if ((int)(threadIdx.x & 63) == leader && mk) atomicAdd(&s_A[rr], __popcll(mk));
+            }
+        } else {
+            atomicAdd(&s_A[r], 1);
+        }
         nd = (uint32_t)r;
     })
     __syncthreads();
@@ -974,6 +1017,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
     __syncthreads();
 
+    const bool packed_rank = n < (1 << 19);
     // ---- splitting steps
     while (true) {
         size = s_var[4];
@@ -994,7 +1038,10 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         }
         if (tid == 0) s_var[7] = 0;
         __syncthreads();
-        // b. child occupancy (DivideNode :431-476)
+        // b. processing order of the parents: index among the flagged nodes, list order (needs only the flags,
+        //    so it runs before the keys are visited and the two passes below share one barrier)
+        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
+        // c. child occupancy (DivideNode :431-476)
         FOR_KEYS({
             int p = (int)(nd & 0x7ff);
             if (s_fl[p]) {
@@ -1006,9 +1053,6 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 nd = (uint32_t)(p | (qd << 11));
             }
         })
-        __syncthreads();
-        // c. processing order of the parents
-        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);   // s_A[p] = index among flagged nodes, list order
         if (!phase2) {
             for (int p = tid; p < size; p += NT)
                 if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
@@ -1018,20 +1062,33 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             for (int p = tid; p < size; p += NT)
                 if (s_fl[p]) {
                     s_cand[s_A[p]] = (unsigned short)p;
-                    s_key[s_A[p]] = (uint32_t)cc_cur[p];     // size
-                    s_B[s_A[p]] = ci_cur[p];                 // creation index (distinct)
+                    // (size, creation index) as one key: creation indices are distinct and below 4 * 2048;
+                    // a level with 2^19 keys or more (sizes that do not fit) compares the two fields instead
+                    s_key[s_A[p]] = packed_rank ? (((uint32_t)cc_cur[p] << 13) | (uint32_t)ci_cur[p]) : (uint32_t)cc_cur[p];
+                    s_B[s_A[p]] = ci_cur[p];
                 }
             __syncthreads();
-            // rank in (size, creation) descending order
-            for (int i = tid; i < m; i += NT) {
-                const uint32_t ki = s_key[i];
-                const int ci = s_B[i];
+            // rank in (size, creation) descending order: G lanes share one candidate's m comparisons
+            int G = 1;
+            while (G < 64 && m * (2 * G) <= NT) G *= 2;
+            for (int i0 = 0; i0 < m; i0 += NT / G) {
+                const int i = i0 + tid / G, sub = tid & (G - 1);
                 int r = 0;
-                for (int j = 0; j < m; j++) {
-                    const uint32_t kj = s_key[j];
-                    r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                if (i < m) {
+                    const uint32_t ki = s_key[i];
+                    if (packed_rank) {
+#pragma unroll 4
+                        for (int j = sub; j < m; j += G) r += s_key[j] > ki;
+                    } else {
+                        const int ci = s_B[i];
+                        for (int j = sub; j < m; j += G) {
+                            const uint32_t kj = s_key[j];
+                            r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                        }
+                    }
                 }
-                s_order[r] = s_cand[i];
+                for (int d = 1; d < G; d <<= 1) r += __shfl_xor(r, d, 64);
+                if (i < m && sub == 0) s_order[r] = s_cand[i];
             }
             __syncthreads();
             // growth of |L| per split, in processing order; first index reaching N
@@ -1061,9 +1118,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         }
         for (int p = tid; p < size; p += NT) s_C[p] = !s_fl[p];
         __syncthreads();
-        const int both = lds_excl_scan<NT>(s_A, norder, s_tmp);
+        int both, nold;
+        lds_excl_scan2<NT>(s_A, norder, s_C, size, s_tmp, &both, &nold);
         const int totalch = both & 0xffff, ncreated = both >> 16;
-        const int nold = lds_excl_scan<NT>(s_C, size, s_tmp);
         const int newsize = totalch + nold;
         // e. build the next list
         for (int s = tid; s < norder; s += NT) {

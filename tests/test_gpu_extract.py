@@ -238,6 +238,43 @@ def test_pyramid_mirror_survives_staging_growth(oracle, euroc_left):
         ex.close()
 
 
+def test_page_locked_caller_buffers(gpu, euroc_left):
+    """Caller buffers that are page-locked are copied from / to directly instead of through the
+    staging area (frames lying back to back go up as one copy, strided ones as a 2-D copy):
+    same results as from ordinary memory."""
+    import ctypes as C
+    import torch
+    from orb_slam_amd.extractor import KP_DTYPE
+    keep = []
+
+    def pinned(shape, dtype):
+        t = torch.empty(int(np.prod(shape)) * np.dtype(dtype).itemsize, dtype=torch.uint8).pin_memory()
+        keep.append(t)
+        return t.numpy().view(dtype).reshape(shape)
+
+    imgs = synthetic_batch(5, 752, 480, seed0=4700)
+    imgs[2] = euroc_left
+    want = gpu.extract_batch(imgs)
+    # input pinned and contiguous, outputs pinned (raw call), then input pinned with a row stride
+    pin_imgs = pinned(imgs.shape, np.uint8)
+    pin_imgs[...] = imgs
+    got = gpu.extract_batch(pin_imgs)
+    for (kw, dw), (kg, dg) in zip(want, got):
+        assert np.array_equal(kw, kg) and np.array_equal(dw, dg)
+    b, h, w = imgs.shape
+    cap = gpu.max_keypoints(w, h)
+    kps, desc, n = pinned((b, cap), KP_DTYPE), pinned((b, cap, 32), np.uint8), np.zeros(b, np.int32)
+    ptrs = (C.c_void_p * b)(*[pin_imgs[i].ctypes.data for i in range(b)])
+    assert gpu._lib.orbx_extract_batch(gpu._ctx, ptrs, b, w, h, w, kps.ctypes.data, desc.ctypes.data, cap, n.ctypes.data) == 0
+    for i, (kw, dw) in enumerate(want):
+        assert n[i] == len(kw) and np.array_equal(kps[i, :n[i]], kw) and np.array_equal(desc[i, :n[i]], dw)
+    wide = pinned((480, 800), np.uint8)
+    wide[...] = 0
+    wide[:, :752] = euroc_left
+    kg, dg = gpu(wide[:, :752])
+    assert np.array_equal(kg, want[2][0]) and np.array_equal(dg, want[2][1])
+
+
 def test_cpp_host_program(oracle, euroc_left, tmp_path):
     """The C++ host class (include/orbx_host.hpp) gives the same result as the oracle."""
     import os

@@ -275,6 +275,41 @@ def test_page_locked_caller_buffers(gpu, euroc_left):
     assert np.array_equal(kg, want[2][0]) and np.array_equal(dg, want[2][1])
 
 
+def test_two_extractors_from_two_threads(euroc_left, euroc_right):
+    """The reference runs the left and the right extractor of a stereo frame on two threads at once
+    (src/Frame.cc:84-87): two contexts called concurrently give what they give one after the other."""
+    import threading
+    from orb_slam_amd import ORBextractor
+    exl, exr = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)
+    try:
+        want = [exl(euroc_left), exr(euroc_right)]
+        errors = []
+
+        def work(ex, img, ref):
+            try:
+                for _ in range(40):
+                    k, d = ex(img)
+                    if not (np.array_equal(k, ref[0]) and np.array_equal(d, ref[1])):
+                        errors.append("result changed under concurrency")
+                        return
+                    if not np.array_equal(ex.pyramid_level(3, border=19), ex.pyramid_level(3, border=19)):
+                        errors.append("pyramid mirror unstable")
+                        return
+            except Exception as e:      # noqa: BLE001 - reported through the list
+                errors.append(repr(e))
+
+        ts = [threading.Thread(target=work, args=(exl, euroc_left, want[0])),
+              threading.Thread(target=work, args=(exr, euroc_right, want[1]))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors
+    finally:
+        exl.close()
+        exr.close()
+
+
 def test_cpp_host_program(oracle, euroc_left, tmp_path):
     """The C++ host class (include/orbx_host.hpp) gives the same result as the oracle."""
     import os

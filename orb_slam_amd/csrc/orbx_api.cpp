@@ -57,6 +57,7 @@ struct orbx_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t aux_stream = nullptr;   // the blur runs here, beside FAST + quadtree
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
+    std::vector<hipEvent_t> ev_up;      // one per chunk of a pipelined host-fed batch
     std::string err;
 
     // geometry of the current frame size
@@ -195,14 +196,28 @@ int ensure_frames(orbx_ctx* c, int nframes)
 }
 
 // the launch sequence; everything asynchronous on c->stream
+// f0: index of the first of these frames inside the context's per-frame buffers (a batch fed from the
+// host runs in chunks; the caller has sized the buffers for all of them before the first chunk)
 int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int stride, size_t frame_stride,
-              orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out, bool pyramid_only)
+              orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out, bool pyramid_only, int f0 = 0)
 {
     int rc = ensure_geometry(c, w, h);
     if (rc != ORBX_OK) return rc;
-    rc = ensure_frames(c, nframes);
+    rc = ensure_frames(c, f0 + nframes);
     if (rc != ORBX_OK) return rc;
     const FrameGeom& g = c->g;
+    const size_t F = (size_t)f0;
+    uint8_t* const pyr = c->pyr.as<uint8_t>() + F * g.pyr_frame_bytes;
+    uint8_t* const blur = c->blur.as<uint8_t>() + F * g.pyr_frame_bytes;
+    uint32_t* const cell_cand = c->cell_cand.as<uint32_t>() + F * g.cand_per_frame;
+    int* const cell_count = c->cell_count.as<int>() + F * g.ncells;
+    int* const cell_off = c->cell_off.as<int>() + F * g.ncells;
+    uint32_t* const key_xy = c->key_xy.as<uint32_t>() + F * g.keys_per_frame;
+    uint8_t* const key_resp = c->key_resp.as<uint8_t>() + F * g.keys_per_frame;
+    uint16_t* const key_node = c->key_node.as<uint16_t>() + F * g.keys_per_frame;
+    uint8_t* const kp_stage = static_cast<uint8_t*>(c->kp_stage.p) + F * (size_t)g.kp_per_frame * 8;
+    int* const level_count = c->level_count.as<int>() + F * kMaxLevels;
+    int* const level_ncand = c->level_ncand.as<int>() + F * kMaxLevels;
     hipStream_t s = c->stream;
     EventSet* es = nullptr;
     if (c->events_ok && c->stage_timing && !pyramid_only) {
@@ -217,17 +232,17 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     auto t1 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->stop[i], q); };
 
     t0(ST_PYR0, s);
-    launch_pyr_level0(d_imgs, stride, frame_stride, c->pyr.as<uint8_t>(), g, nframes, s);
+    launch_pyr_level0(d_imgs, stride, frame_stride, pyr, g, nframes, s);
     t1(ST_PYR0, s);
     t0(ST_RESIZE, s);
     static const bool old_resize = getenv("ORBX_OLD_RESIZE") != nullptr;
     const bool slide = g.resize_slide_ok && !old_resize;
     for (int l = 1; l < g.nlevels; l++) {
-        if (slide) launch_resize_slide(c->pyr.as<uint8_t>(), g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
-        else launch_pyr_resize(c->pyr.as<uint8_t>(), g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
+        if (slide) launch_resize_slide(pyr, g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
+        else launch_pyr_resize(pyr, g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
     }
     t1(ST_RESIZE, s);
-    c->last_nframes = nframes;
+    c->last_nframes = f0 + nframes;
     c->have_pyramid = true;
     c->have_features = false;
     c->h_pyr_frame = -1;
@@ -236,7 +251,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         return ORBX_OK;
     }
     t0(ST_FAST, s);
-    launch_fast_cells_wave(c->pyr.as<uint8_t>(), g, c->fast_lds, c->fast_cells.as<FastCell>(), c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), nframes, s);
+    launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
     t1(ST_FAST, s);
     // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
     // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
@@ -247,18 +262,16 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipStreamWaitEvent(bs, c->ev_pyr, 0));
     }
     t0(ST_BLUR, bs);
-    launch_blur_slide(c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), g, c->blur_map, nframes, bs);
+    launch_blur_slide(pyr, blur, g, c->blur_map, nframes, bs);
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);
-    launch_quadtree(g, c->cell_cand.as<uint32_t>(), c->cell_count.as<int>(), c->cell_off.as<int>(),
-                    c->key_xy.as<uint32_t>(), c->key_resp.as<uint8_t>(), c->key_node.as<uint16_t>(), c->kp_stage.p,
-                    c->level_count.as<int>(), c->level_ncand.as<int>(), nframes, s);
+    launch_quadtree(g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand,
+                    nframes, s);
     t1(ST_QUADTREE, s);
     if (overlap) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     t0(ST_DESC, s);
-    launch_orient_desc(g, c->pyr.as<uint8_t>(), c->blur.as<uint8_t>(), c->kp_stage.p, c->level_count.as<int>(),
-                       d_kps, d_desc, cap, d_n_out, nframes, s);
+    launch_orient_desc(g, pyr, blur, kp_stage, level_count, d_kps, d_desc, cap, d_n_out, nframes, s);
     t1(ST_DESC, s);
     if (es) es->pending = true;
     HIPCHECK(c, hipGetLastError());
@@ -326,18 +339,19 @@ hipError_t h2d(orbx_ctx* c, void* dev, const void* host, size_t bytes)
 }
 
 // h rows of w bytes, source rows `stride` apart, packed tightly on the device
-hipError_t h2d_rows(orbx_ctx* c, void* dev, const uint8_t* host, size_t stride, size_t w, size_t h)
+hipError_t h2d_rows(orbx_ctx* c, void* dev, const uint8_t* host, size_t stride, size_t w, size_t h, hipStream_t q = nullptr)
 {
     if (w == 0 || h == 0) return hipSuccess;
+    if (!q) q = c->stream;
     if (host_is_pinned(host, w * h))
-        return stride == w ? hipMemcpyAsync(dev, host, w * h, hipMemcpyHostToDevice, c->stream)
-                           : hipMemcpy2DAsync(dev, w, host, stride, w, h, hipMemcpyHostToDevice, c->stream);
+        return stride == w ? hipMemcpyAsync(dev, host, w * h, hipMemcpyHostToDevice, q)
+                           : hipMemcpy2DAsync(dev, w, host, stride, w, h, hipMemcpyHostToDevice, q);
     size_t off;
     hipError_t e = arena_reserve(c, w * h, &off);
     if (e != hipSuccess) return e;
     if (stride == w) std::memcpy(c->pin + off, host, w * h);
     else for (size_t r = 0; r < h; r++) std::memcpy(c->pin + off + r * w, host + r * stride, w);
-    return hipMemcpyAsync(dev, c->pin + off, w * h, hipMemcpyHostToDevice, c->stream);
+    return hipMemcpyAsync(dev, c->pin + off, w * h, hipMemcpyHostToDevice, q);
 }
 
 hipError_t d2h(orbx_ctx* c, void* host, const void* dev, size_t bytes)
@@ -440,6 +454,7 @@ void orbx_destroy(orbx_ctx* c)
     if (c->events_ok)
         for (int i = 0; i < kEventSets; i++)
             for (int j = 0; j < ST_COUNT; j++) { (void)hipEventDestroy(c->evs[i].start[j]); (void)hipEventDestroy(c->evs[i].stop[j]); }
+    for (hipEvent_t ev : c->ev_up) (void)hipEventDestroy(ev);
     if (c->ev_pyr) (void)hipEventDestroy(c->ev_pyr);
     if (c->ev_blur) (void)hipEventDestroy(c->ev_blur);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
@@ -534,18 +549,68 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
     HIPCHECK(c, c->out_n.ensure(n * 4));
     for (int f = 0; f < nframes; f++)
         if (!imgs[f]) return fail(c, ORBX_ERR_INVALID, "null frame pointer");
-    for (int f = 0; f < nframes;) {
-        // frames that lie back to back in host memory (one array holding the batch) go up as one copy:
-        // a copy per 361 KB frame spends as long on its set-up as on its bytes
-        int e = f + 1;
-        if (stride == w)
-            while (e < nframes && e - f < 64 && imgs[e] == imgs[e - 1] + fbytes) e++;
-        HIPCHECK(c, h2d_rows(c, c->in.as<uint8_t>() + f * fbytes, imgs[f], stride, w, (size_t)h * (e - f)));
-        f = e;
+    // uploads frames [f_lo, f_hi) on stream q; frames that lie back to back in host memory (one array
+    // holding the batch) go up as one copy: a copy per 361 KB frame spends as long on its set-up as on
+    // its bytes
+    auto upload = [&](int f_lo, int f_hi, hipStream_t q) -> hipError_t {
+        for (int f = f_lo; f < f_hi;) {
+            int e = f + 1;
+            if (stride == w)
+                while (e < f_hi && imgs[e] == imgs[e - 1] + fbytes) e++;
+            hipError_t err = h2d_rows(c, c->in.as<uint8_t>() + f * fbytes, imgs[f], stride, w, (size_t)h * (e - f), q);
+            if (err != hipSuccess) return err;
+            f = e;
+        }
+        return hipSuccess;
+    };
+    // A large batch is transfer-bound, so it runs in chunks: the upload of one chunk (second stream)
+    // overlaps the kernels of the previous one.  Buffers and the staging area are sized for the whole
+    // batch first, so that nothing is reallocated while copies are in flight.
+    constexpr int kChunk = 64;
+    const int nchunks = (nframes + kChunk - 1) / kChunk;
+    static const bool no_pipe = getenv("ORBX_NO_PIPELINE") != nullptr;
+    bool pipelined = nframes >= 2 * kChunk && c->aux_stream && !no_pipe;
+    if (pipelined) {
+        while ((int)c->ev_up.size() < nchunks) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { pipelined = false; break; }
+            c->ev_up.push_back(ev);
+        }
     }
-    rc = run_batch(c, c->in.as<uint8_t>(), nframes, w, h, w, fbytes, c->out_kps.as<orbx_keypoint>(),
-                   c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false);
-    if (rc != ORBX_OK) return rc;
+    if (pipelined) {
+        rc = ensure_geometry(c, w, h);
+        if (rc != ORBX_OK) return rc;
+        rc = ensure_frames(c, nframes);
+        if (rc != ORBX_OK) return rc;
+        {   // staging for everything that is not page-locked, reserved (and released again) in one piece
+            size_t need = 4 * n + 4096;
+            if (!host_is_pinned(imgs[0], fbytes)) need += n * (fbytes + 64);
+            if (!host_is_pinned(kps, n * cap_per_frame * sizeof(orbx_keypoint))) need += n * cap_per_frame * sizeof(orbx_keypoint);
+            if (!host_is_pinned(desc, n * cap_per_frame * 32)) need += n * cap_per_frame * 32;
+            size_t off;
+            HIPCHECK(c, arena_reserve(c, need, &off));
+            c->pin_used = off;
+        }
+        // the second stream starts after everything already queued on the first one (table uploads, memsets)
+        HIPCHECK(c, hipEventRecord(c->ev_up[0], c->stream));
+        HIPCHECK(c, hipStreamWaitEvent(c->aux_stream, c->ev_up[0], 0));
+        for (int k = 0; k < nchunks; k++) {
+            const int f0 = k * kChunk, m = std::min(kChunk, nframes - f0);
+            HIPCHECK(c, upload(f0, f0 + m, c->aux_stream));
+            HIPCHECK(c, hipEventRecord(c->ev_up[k], c->aux_stream));
+            HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_up[k], 0));
+            rc = run_batch(c, c->in.as<uint8_t>() + (size_t)f0 * fbytes, m, w, h, w, fbytes,
+                           c->out_kps.as<orbx_keypoint>() + (size_t)f0 * cap_per_frame,
+                           c->out_desc.as<uint8_t>() + (size_t)f0 * cap_per_frame * 32, cap_per_frame,
+                           c->out_n.as<int32_t>() + f0, false, f0);
+            if (rc != ORBX_OK) return rc;
+        }
+    } else {
+        HIPCHECK(c, upload(0, nframes, c->stream));
+        rc = run_batch(c, c->in.as<uint8_t>(), nframes, w, h, w, fbytes, c->out_kps.as<orbx_keypoint>(),
+                       c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false);
+        if (rc != ORBX_OK) return rc;
+    }
     HIPCHECK(c, d2h(c, n_out, c->out_n.p, n * 4));
     HIPCHECK(c, d2h(c, kps, c->out_kps.p, n * cap_per_frame * sizeof(orbx_keypoint)));
     HIPCHECK(c, d2h(c, desc, c->out_desc.p, n * cap_per_frame * 32));

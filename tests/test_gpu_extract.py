@@ -238,6 +238,25 @@ def test_pyramid_mirror_survives_staging_growth(oracle, euroc_left):
         ex.close()
 
 
+def test_pipelined_host_batch(gpu, oracle, euroc_left):
+    """Host-fed batches of 128 frames and more run in chunks of 64 whose uploads overlap the kernels
+    of the previous chunk: 130 frames (two chunks and a short one), every chunk checked against
+    single-frame extraction, and the pyramids of all chunks stay readable afterwards."""
+    base = synthetic_batch(13, 752, 480, seed0=4800)
+    imgs = np.ascontiguousarray(np.concatenate([base] * 10))
+    imgs[129] = euroc_left
+    res = gpu.extract_batch(imgs)
+    oracle.compute_pyramid(euroc_left)
+    assert np.array_equal(gpu.pyramid_level(2, frame=129, border=19), oracle.pyramid_plane(2))
+    first = gpu.pyramid_level(1, frame=5).copy()
+    assert np.array_equal(gpu.pyramid_level(1, frame=5 + 65), first)       # same image, another chunk
+    for i in (0, 63, 64, 127, 128, 129):
+        k1, d1 = gpu(imgs[i])
+        assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), i
+    for i in range(13, 130 - 1):
+        assert np.array_equal(res[i][1], res[i % 13][1]), i
+
+
 def test_page_locked_caller_buffers(gpu, euroc_left):
     """Caller buffers that are page-locked are copied from / to directly instead of through the
     staging area (frames lying back to back go up as one copy, strided ones as a 2-D copy):

@@ -136,6 +136,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    ex.set_stage_timing(True)
     ex.reset_stage_times()
     t0 = time.perf_counter()
     for _ in range(args.steps):

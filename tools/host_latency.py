@@ -27,6 +27,10 @@ def main():
     t = np.array(t) * 1e6
     print("orbx_extract, 752x480, one frame: median %.0f us, p90 %.0f us, min %.0f us (%d keypoints)" %
           (np.median(t), np.percentile(t, 90), t.min(), len(k)))
+    ex.set_stage_timing(True)          # a second pass with the per-stage events in the launch sequence
+    ex.reset_stage_times()
+    for i in range(n):
+        ex(imgs[i % 8])
     st = ex.stage_times()
     print("  GPU stages (us): " + "  ".join("%s %.0f" % (s, 1e3 * v[0] / max(1, v[1])) for s, v in st.items()))
 

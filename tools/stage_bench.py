@@ -33,6 +33,7 @@ def main():
     for _ in range(3):
         ex.extract_batch_device(d_imgs, B, W, H, W, W * H, d_kps, d_desc, cap, d_n)
     torch.cuda.synchronize()
+    ex.set_stage_timing(True)
     ex.reset_stage_times()
     t0 = torch.cuda.Event(enable_timing=True)
     t1 = torch.cuda.Event(enable_timing=True)

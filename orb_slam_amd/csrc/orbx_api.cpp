@@ -250,8 +250,16 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipGetLastError());
         return ORBX_OK;
     }
+    // The blur rides in the FAST launch: both only need the finished pyramid, one is bound by vector
+    // issue and the other by memory, and a lone frame saves a dependent launch.  ORBX_FUSE_MAX (read per
+    // call: a test switches it) limits the fusion to batches of at most that many frames.
+    const char* e_fuse = getenv("ORBX_FUSE_MAX");
+    const bool fused = (!e_fuse || nframes <= atoi(e_fuse)) && !overlap && g.ncells > 0;
     t0(ST_FAST, s);
-    launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
+    if (fused)
+        launch_fast_blur(pyr, blur, g, c->fast_lds, c->blur_map, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
+    else
+        launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
     t1(ST_FAST, s);
     // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
     // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
@@ -262,7 +270,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipStreamWaitEvent(bs, c->ev_pyr, 0));
     }
     t0(ST_BLUR, bs);
-    launch_blur_slide(pyr, blur, g, c->blur_map, nframes, bs);
+    if (!fused) launch_blur_slide(pyr, blur, g, c->blur_map, nframes, bs);
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);

@@ -272,12 +272,10 @@ __device__ __forceinline__ uint32_t blur_vsum(uint32_t h0, uint32_t h1, uint32_t
     return acc > 255u ? 255u : acc;
 }
 
-__global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                                    FrameGeom g, SlideMap sm)
+// one work item (level, 64-dword column block, row band) on one wavefront; item and frame are wave-uniform
+__device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                          const FrameGeom& g, const SlideMap& sm, int item, int lane, int frame)
 {
-    const int lane = threadIdx.x & 63;
-    // wave-uniform: level, band and column block live in scalar registers
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (item >= sm.base[kMaxLevels]) return;
     int level = 0;
 #pragma unroll
@@ -292,7 +290,7 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
     const int rb = ndw == 1 ? flat : (int)__umulhi((uint32_t)flat, sm.rcp_ndw[level]);   // band
     const int dw = flat - rb * ndw;                      // dword column inside the level image
     const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
-    const size_t fbase = (size_t)blockIdx.y * g.pyr_frame_bytes + L.plane_off;
+    const size_t fbase = (size_t)frame * g.pyr_frame_bytes + L.plane_off;
     // addresses = wave-uniform plane pointer + the lane's 32-bit offset (scalar base + vector offset
     // in the load / store, one 32-bit add per row instead of 64-bit vector arithmetic)
     const uint8_t* src = pyr + fbase;
@@ -349,6 +347,14 @@ __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ 
             *reinterpret_cast<uint32_t*>(dst + (size_t)(dofs + __umul24((uint32_t)p, pitch))) = lo | (hi << 16);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                                    FrameGeom g, SlideMap sm)
+{
+    // wave-uniform: level, band and column block live in scalar registers
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    blur_item(pyr, blur, g, sm, item, threadIdx.x & 63, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------
@@ -735,6 +741,34 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         f = blockIdx.y;
     }
     fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, cell, f, smem);
+}
+
+// FAST and the blur in one launch: both only need the finished pyramid, so the blur's work items ride
+// along as extra one-wavefront workgroups behind the cells.  A lone frame saves one launch of its
+// chain of dependent launches; in a batch the two overlap because one is bound by vector issue and
+// the other by memory (measured: the fused launch takes what the two took, and the descriptor kernel
+// that follows finds more of the blurred planes in cache).
+template <int TPC = 0, int SPC = 0>
+__global__ __launch_bounds__(64) void k_fast_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, FrameGeom g,
+                                                  FastLds fl, SlideMap sm, uint32_t* __restrict__ cell_cand,
+                                                  int* __restrict__ cell_count, const FastCell* __restrict__ cells,
+                                                  int frame_per_xcd, unsigned long long rcp_nitems, int nitems, int nframes)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    // large batches: every frame on one XCD, as in k_fast_cells_wave (nitems = cells + blur items per frame)
+    int b, f;
+    if (frame_per_xcd) {
+        const uint32_t seq = blockIdx.x >> 3;
+        const uint32_t fq = (uint32_t)(((unsigned long long)seq * rcp_nitems) >> 40);    // seq / nitems
+        b = (int)(seq - fq * (uint32_t)nitems);
+        f = (int)(fq * 8 + (blockIdx.x & 7));
+        if (f >= nframes) return;
+    } else {
+        b = blockIdx.x;
+        f = blockIdx.y;
+    }
+    if (b < g.ncells) fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, b, f, smem);
+    else blur_item(pyr, blur, g, sm, b - g.ncells, threadIdx.x, f);
 }
 
 #undef WAVE_SYNC
@@ -1524,6 +1558,22 @@ void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
         }
     }
     sm.base[kMaxLevels] = base;
+}
+
+void launch_fast_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const FastLds& fl, const SlideMap& sm,
+                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s)
+{
+    const int nitems = g.ncells + sm.base[kMaxLevels];
+    static const int env_map = getenv("ORBX_FAST_XCD_MAP") ? atoi(getenv("ORBX_FAST_XCD_MAP")) : -1;
+    const int per_xcd = env_map >= 0 ? env_map : (nframes >= 32);
+    const unsigned long long rcp = ((1ull << 40) + (unsigned long long)nitems - 1) / (unsigned long long)nitems;
+    dim3 grid = per_xcd ? dim3((unsigned)(8 * nitems * ((nframes + 7) / 8))) : dim3(nitems, nframes);
+    if (fl.fixed_pitch)
+        hipLaunchKernelGGL((k_fast_blur<kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr, blur, g,
+                           fl, sm, cell_cand, cell_count, cells, per_xcd, rcp, nitems, nframes);
+    else
+        hipLaunchKernelGGL(k_fast_blur<>, grid, dim3(64), (size_t)fl.total, s, pyr, blur, g, fl, sm, cell_cand, cell_count,
+                           cells, per_xcd, rcp, nitems, nframes);
 }
 
 void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,

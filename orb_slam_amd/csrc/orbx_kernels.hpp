@@ -35,6 +35,8 @@ void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* 
 void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
                          int nframes, hipStream_t s);
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm);
+void launch_fast_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const FastLds& fl, const SlideMap& sm,
+                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s);
 void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
                        hipStream_t s);
 void make_fast_lds(const FrameGeom& g, FastLds& fl);

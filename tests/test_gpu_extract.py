@@ -156,6 +156,19 @@ def test_fast_queue_overflow_path(oracle, monkeypatch):
     ex.close()
 
 
+def test_separate_fast_and_blur_launches(gpu, oracle, euroc_left, monkeypatch):
+    """By default the blur's work items ride in the FAST launch; ORBX_FUSE_MAX=0 runs the two kernels
+    on their own: same results, stage by stage."""
+    monkeypatch.setenv("ORBX_FUSE_MAX", "0")
+    imgs = synthetic_batch(3, 752, 480, seed0=4900)
+    imgs[1] = euroc_left
+    res = gpu.extract_batch(imgs)
+    for i in range(3):
+        kps_o, desc_o = _compare_frame(gpu, oracle, imgs[i], frame=i)
+        _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+        assert np.array_equal(res[i][1], desc_o)
+
+
 def test_fast_variable_pitch_kernel(oracle, euroc_left, monkeypatch):
     """Cells wider than 36 pixels run the FAST kernel with run-time LDS pitches instead of the
     compiled-in ones.  Force that kernel on the usual geometry: identical results, stage by stage."""

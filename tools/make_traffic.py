@@ -13,7 +13,7 @@ import json
 import sys
 
 STAGE_OF = {"k_pyr_level0": "pyr_level0", "k_resize_slide": "pyr_resize", "k_blur_slide": "blur",
-            "k_fast_cells_wave": "fast_cells", "k_quadtree": "quadtree", "k_orient_desc": "orient_desc"}
+            "k_fast_cells_wave": "fast_cells", "k_fast_blur": "fast_blur", "k_quadtree": "quadtree", "k_orient_desc": "orient_desc"}
 
 
 def per_step(path, counter):

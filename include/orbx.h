@@ -121,7 +121,9 @@ int orbx_debug_level_counts(orbx_ctx *ctx, int frame, int32_t *counts);
 int orbx_debug_blurred_level(orbx_ctx *ctx, int frame, int level, uint8_t *out, size_t out_size);
 /* Per-stage GPU time of the batch calls since the last reset, measured with
  * HIP events on the context's stream. names: static strings; returns the
- * number of stages written (<= cap). Synchronises the stream. */
+ * number of stages written (<= cap). Synchronises the stream. The blur's work
+ * items normally ride in the FAST launch: their time is then part of "fast_cells" and
+ * "blur" stays near zero. */
 int orbx_stage_times(orbx_ctx *ctx, const char **names, float *total_ms, int32_t *launches, int cap);
 int orbx_reset_stage_times(orbx_ctx *ctx);
 /* Stage timing is off by default; enable = 1 adds seven event records to the launch sequence of

@@ -417,6 +417,13 @@ __device__ __forceinline__ us2_t pk_min_u16(us2_t a, uint32_t b)
     asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b));
     return r;
 }
+// a * b + c on two 16-bit lanes (b: both halves in an SGPR); the compiler splits it into shift and add
+__device__ __forceinline__ us2_t pk_mad_u16(us2_t a, uint32_t b, uint32_t c)
+{
+    us2_t r;
+    asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
+    return r;
+}
 // max(br, dk) of the compass test, clamped at 0, for two pixels
 __device__ __forceinline__ us2_t compass2(us2_t v, us2_t p0, us2_t p8, us2_t p4, us2_t p12)
 {
@@ -533,7 +540,9 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         const int nv = cw - c4;                             // valid pixels of this lane's group: columns < cw
         const uint32_t colE = (nv > 0 ? 0x0000ffffu : 0u) | (nv > 2 ? 0xffff0000u : 0u);
         const uint32_t colO = (nv > 1 ? 0x0000ffffu : 0u) | (nv > 3 ? 0xffff0000u : 0u);
-        const us2_t t2 = {(unsigned short)t, (unsigned short)t}, ts2 = {(unsigned short)ts, (unsigned short)ts};
+        const us2_t ts2 = {(unsigned short)ts, (unsigned short)ts};
+        const uint32_t t32 = (uint32_t)t | ((uint32_t)t << 16);
+        const uint32_t thrE = t32 | ~colE, thrO = t32 | ~colO;      // per-lane thresholds, 0xffff where the column is invalid
         const uint32_t one2 = 0x00010001u;
         const int step_w = __mul24(R, TPW);
         for (int y0 = 0; y0 < ch; y0 += R) {
@@ -549,14 +558,17 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
             const uint32_t a4 = __builtin_amdgcn_alignbyte(q4[TPW3 + 1], q4[TPW3], j4 & 3);
             const us2_t mE = compass2(even_bytes(av), even_bytes(a0), even_bytes(a8), even_bytes(a4), even_bytes(a12));
             const us2_t mO = compass2(odd_bytes(av), odd_bytes(a0), odd_bytes(a8), odd_bytes(a4), odd_bytes(a12));
+            // invalid pixels (columns past the cell, rows past it in the last round) get the threshold 0xffff:
+            // their saturated difference is 0
             const bool row_ok = row < ch;
-            const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, t2)) & (row_ok ? colE : 0u);
-            const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, t2)) & (row_ok ? colO : 0u);
+            const us2_t tE = __builtin_bit_cast(us2_t, row_ok ? thrE : 0xffffffffu), tO = __builtin_bit_cast(us2_t, row_ok ? thrO : 0xffffffffu);
+            const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, tE));
+            const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, tO));
             const us2_t cE = pk_min_u16(__builtin_bit_cast(us2_t, dE), one2);          // 1 per survivor
             const us2_t cO = pk_min_u16(__builtin_bit_cast(us2_t, dO), one2);
-            const us2_t sE = pk_min_u16(__builtin_elementwise_sub_sat(mE, ts2), one2) << (unsigned short)15;
-            const us2_t sO = pk_min_u16(__builtin_elementwise_sub_sat(mO, ts2), one2) << (unsigned short)15;
-            const us2_t eE = __builtin_bit_cast(us2_t, idxE) + sE, eO = __builtin_bit_cast(us2_t, idxO) + sO;
+            // entry = index + 0x8000 * (pretest value above iniThFAST): one packed multiply-add per pair
+            const us2_t eE = pk_mad_u16(pk_min_u16(__builtin_elementwise_sub_sat(mE, ts2), one2), 0x80008000u, idxE);
+            const us2_t eO = pk_mad_u16(pk_min_u16(__builtin_elementwise_sub_sat(mO, ts2), one2), 0x80008000u, idxO);
             const uint32_t both = __builtin_bit_cast(uint32_t, cE) + __builtin_bit_cast(uint32_t, cO);
             const int cnt = (int)((both & 0xffffu) + (both >> 16));
             const int incl = wave_incl_scan(cnt);

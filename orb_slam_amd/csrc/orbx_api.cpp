@@ -59,6 +59,7 @@ struct orbx_ctx {
     hipStream_t aux_stream = nullptr;   // the blur runs here, beside FAST + quadtree
     hipEvent_t ev_pyr = nullptr, ev_blur = nullptr;
     std::vector<hipEvent_t> ev_up;      // one per chunk of a pipelined host-fed batch
+    bool aux_busy = false;              // uploads were queued on aux_stream since the last finish()
     std::string err;
 
     // geometry of the current frame size
@@ -320,6 +321,7 @@ hipError_t arena_reserve(orbx_ctx* c, size_t bytes, size_t* off)
     if (need > c->pin_cap) {
         // everything enqueued so far refers to the old block: drain it first
         hipError_t e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess && c->aux_busy) e = hipStreamSynchronize(c->aux_stream);
         if (e != hipSuccess) return e;
         for (const auto& pd : c->pin_pending) big_memcpy(pd.dst, c->pin + pd.off, pd.bytes);
         c->pin_pending.clear();
@@ -401,6 +403,11 @@ hipError_t d2h(orbx_ctx* c, void* host, const void* dev, size_t bytes)
 hipError_t finish(orbx_ctx* c)
 {
     hipError_t e = hipStreamSynchronize(c->stream);
+    if (c->aux_busy) {      // normally complete already (the first stream waited for every upload); matters after an error
+        const hipError_t e2 = hipStreamSynchronize(c->aux_stream);
+        if (e == hipSuccess) e = e2;
+        c->aux_busy = false;
+    }
     if (e == hipSuccess)
         for (const auto& pd : c->pin_pending) big_memcpy(pd.dst, c->pin + pd.off, pd.bytes);
     c->pin_pending.clear();
@@ -648,6 +655,7 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
         // the second stream starts after everything already queued on the first one (table uploads, memsets)
         HIPCHECK(c, hipEventRecord(c->ev_up[0], c->stream));
         HIPCHECK(c, hipStreamWaitEvent(c->aux_stream, c->ev_up[0], 0));
+        c->aux_busy = true;
         for (int k = 0; k < nchunks; k++) {
             const int f0 = k * kChunk, m = std::min(kChunk, nframes - f0);
             HIPCHECK(c, upload(f0, f0 + m, c->aux_stream));

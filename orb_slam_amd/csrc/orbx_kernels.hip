@@ -4,9 +4,11 @@
 //   k_pyr_level0       copyMakeBorder of the input into level 0        (src/ORBextractor.cc:1212-1213)
 //   k_resize_slide     level l from level l-1 + REFLECT_101 border     (:1205-1208)
 //                      (k_pyr_resize: same result, for scale factors whose 4-pixel source window exceeds 8 bytes)
-//   k_fast_cells_wave  per-cell FAST-9/16 + NMS + threshold fallback   (:1052-1101)
-//   k_blur_slide       7x7 Gaussian of every level                     (:1169-1170)
+//   k_fast_blur        per-cell FAST-9/16 + NMS + threshold fallback   (:1052-1101) and, as further
+//                      workgroups of the same launch, the 7x7 Gaussian of every level (:1169-1170)
+//                      (k_fast_cells_wave and k_blur_slide: the two on their own)
 //   k_quadtree         DistributeOctTree                               (:488-711)
+//                      (k_quadtree_wide: 1024-thread shape for a handful of frames)
 //   k_orient_desc      IC_Angle + rBRIEF + output assembly             (:74-150, :1109-1124, :1173-1188)
 //
 // All arithmetic that decides a result is integer, or float written with

@@ -591,7 +591,7 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     }
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
     int base = 0;
-    if (!flushed) {
+    if (!flushed && nq > 64) {       // up to 64 survivors are one round of scores anyway
         // Only pixels whose pretest value exceeds iniThFAST (the score is below the pretest value) can be
         // corners of the reference's first cv::FAST call, and a neighbour that is not among them cannot
         // out-score one that is.  They are copied, in order, behind the queue, scored, and their strict

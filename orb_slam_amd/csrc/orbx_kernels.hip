@@ -1249,6 +1249,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 // a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
 __global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs>(QUADTREE_ARGS); }
 __global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide>(QUADTREE_ARGS); }
+// 512 threads x 5 register keys: between the two, for batches that fill the device only once
+__global__ __launch_bounds__(512) void k_quadtree_mid(QUADTREE_PARAMS) { quadtree_body<512, 5>(QUADTREE_ARGS); }
 #undef QUADTREE_ARGS
 #undef QUADTREE_PARAMS
 
@@ -1620,12 +1622,17 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
     size_t lds = quadtree_total_lds(g, &off_in_lds);
-    // up to one workgroup per CU (32 frames x 8 levels) the wide shape is faster, beyond that the narrow one (measured)
+    // up to one workgroup per CU (32 frames x 8 levels) the wide shape is fastest, up to about 112 frames the
+    // 512-thread one, beyond that the narrow one (measured: 0.040 against 0.052 ms at 64 frames, 0.106 against 0.061 at 256)
     // read per launch (a test switches it inside one process)
     const char* e_wide = getenv("ORBX_QT_WIDE_MAX");
-    const int wide_max = e_wide ? atoi(e_wide) : 32;
+    const char* e_mid = getenv("ORBX_QT_MID_MAX");
+    const int wide_max = e_wide ? atoi(e_wide) : 32, mid_max = e_mid ? atoi(e_mid) : 112;
     if (nframes <= wide_max)
         hipLaunchKernelGGL(k_quadtree_wide, grid, dim3(1024), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+    else if (nframes <= mid_max)
+        hipLaunchKernelGGL(k_quadtree_mid, grid, dim3(512), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
                            key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
     else
         hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
@@ -1641,6 +1648,9 @@ int quadtree_prepare(int max_nodes)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_wide),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_mid),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
     }

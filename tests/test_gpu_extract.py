@@ -129,15 +129,17 @@ def test_other_geometries(size, nfeat):
 
 
 def test_quadtree_batch_shape_on_small_batch(gpu, oracle, monkeypatch):
-    """Small batches run the quadtree on 1024-thread workgroups, large ones on 256-thread ones.
-    Force the large-batch shape on a small batch: same keypoints."""
-    monkeypatch.setenv("ORBX_QT_WIDE_MAX", "0")
+    """Small batches run the quadtree on 1024-thread workgroups, medium ones on 512-thread and large
+    ones on 256-thread ones.  Force the other two shapes on a small batch: same keypoints."""
     imgs = synthetic_batch(2, 752, 480, seed0=4300)
-    res = gpu.extract_batch(imgs)
-    for i in range(2):
-        kps_o, desc_o = _compare_frame(gpu, oracle, imgs[i], frame=i)
-        _assert_features(res[i][0], res[i][1], kps_o, desc_o)
-        assert np.array_equal(res[i][1], desc_o)
+    for mid_max in ("0", "1000"):          # the 256-thread shape, then the 512-thread one
+        monkeypatch.setenv("ORBX_QT_WIDE_MAX", "0")
+        monkeypatch.setenv("ORBX_QT_MID_MAX", mid_max)
+        res = gpu.extract_batch(imgs)
+        for i in range(2):
+            kps_o, desc_o = _compare_frame(gpu, oracle, imgs[i], frame=i)
+            _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+            assert np.array_equal(res[i][1], desc_o)
 
 
 def test_fast_queue_overflow_path(oracle, monkeypatch):

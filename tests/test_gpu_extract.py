@@ -270,6 +270,14 @@ def test_pipelined_host_batch(gpu, oracle, euroc_left):
         assert np.array_equal(res[i][0], k1) and np.array_equal(res[i][1], d1), i
     for i in range(13, 130 - 1):
         assert np.array_equal(res[i][1], res[i % 13][1]), i
+    # the same batch from page-locked memory (direct chunk uploads instead of staged ones)
+    import torch
+    t = torch.empty(imgs.nbytes, dtype=torch.uint8).pin_memory()
+    pin = t.numpy().reshape(imgs.shape)
+    pin[...] = imgs
+    res2 = gpu.extract_batch(pin)
+    for i in range(130):
+        assert np.array_equal(res2[i][0], res[i][0]) and np.array_equal(res2[i][1], res[i][1]), i
 
 
 def test_page_locked_caller_buffers(gpu, euroc_left):

@@ -136,7 +136,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ex.set_stage_timing(True)
+    # timed region: HIP events only around the launch that dominates (FAST + blur); every stage event
+    # costs a little, and the roofline needs just this one duration
+    ex.set_stage_timing(2)
     ex.reset_stage_times()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -148,7 +150,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    dom_timed = ex.stage_times()["fast_cells"]
+    # per-stage breakdown: a few more steps outside the timed region with every stage bracketed
+    ex.set_stage_timing(1)
+    ex.reset_stage_times()
+    for _ in range(min(args.steps, 5)):
+        step()
+    barrier()
     stages = ex.stage_times()
+    ex.set_stage_timing(0)
     nkp = d_n.cpu().numpy()
     fps = world * B * args.steps / elapsed
 
@@ -160,6 +170,8 @@ def main():
     # dominant kernel and its roofline (HIP events on the launch stream, same timed region)
     dom = max(stages, key=lambda k: stages[k][0])
     dom_ms = stages[dom][0] / max(1, stages[dom][1])
+    if dom in ("fast_blur", "fast_cells") and dom_timed[1] > 0:
+        dom_ms = dom_timed[0] / dom_timed[1]        # the duration measured inside the timed region
     stage_bytes = {  # algorithmic bytes per frame of each stage (terms of the path formula)
         "pyr_level0": W * H + W * H,
         "pyr_resize": 2 * PYRAMID_PIXELS - W * H - 210 * 134,
@@ -192,6 +204,8 @@ def main():
                                "(1000 features, 8 levels, scale 1.2, FAST 20/7), inputs resident in HBM" % B,
                    "frames_per_batch": B, "mean_keypoints_per_frame": round(float(nkp.mean()), 1)},
         "stage_ms_per_step": {k: round(v[0] / max(1, v[1]), 4) for k, v in stages.items()},
+        "stage_ms_note": "every stage bracketed, %d extra steps after the timed region; roofline.kernel_ms is from the "
+                         "timed region itself" % min(args.steps, 5),
         "roofline": roofline,
     }
 

@@ -127,7 +127,8 @@ int orbx_debug_blurred_level(orbx_ctx *ctx, int frame, int level, uint8_t *out, 
 int orbx_stage_times(orbx_ctx *ctx, const char **names, float *total_ms, int32_t *launches, int cap);
 int orbx_reset_stage_times(orbx_ctx *ctx);
 /* Stage timing is off by default; enable = 1 adds seven event records to the launch sequence of
- * every batch call (about 10 us for a lone frame) and makes orbx_stage_times report them. */
+ * every batch call (about 10 us for a lone frame) and makes orbx_stage_times report them;
+ * enable = 2 brackets only the FAST (+ blur) launch, the longest one (two records). */
 int orbx_set_stage_timing(orbx_ctx *ctx, int enable);
 
 /* --- matching -------------------------------------------------------------- */

@@ -48,6 +48,7 @@ struct EventSet {
     hipEvent_t start[ST_COUNT], stop[ST_COUNT];
     bool pending = false;
     bool chained = false;   // stages ran back to back on one stream: stop[i-1] doubles as start[i]
+    bool only_fast = false; // only the FAST (+ blur) launch was bracketed
 };
 
 } // namespace
@@ -94,7 +95,7 @@ struct orbx_ctx {
     // stage timing
     EventSet evs[kEventSets];
     bool events_ok = false;
-    bool stage_timing = false;     // per-stage events cost about 10 us per call: opt-in (orbx_set_stage_timing)
+    int stage_timing = 0;          // 0 off, 1 every stage, 2 only the FAST (+ blur) launch; events cost about 10 us per call: opt-in
     int ev_next = 0;
     double stage_ms[ST_COUNT] = {0};
     int stage_launches[ST_COUNT] = {0};
@@ -125,6 +126,16 @@ int fail_hip(orbx_ctx* c, const char* what, hipError_t e)
 void harvest(orbx_ctx* c, EventSet& es)
 {
     if (!es.pending) return;
+    if (es.only_fast) {
+        (void)hipEventSynchronize(es.stop[ST_FAST]);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, es.start[ST_FAST], es.stop[ST_FAST]) == hipSuccess) {
+            c->stage_ms[ST_FAST] += ms;
+            c->stage_launches[ST_FAST] += 1;
+        }
+        es.pending = false;
+        return;
+    }
     (void)hipEventSynchronize(es.stop[ST_DESC]);
     (void)hipEventSynchronize(es.stop[ST_BLUR]);
     for (int s = 0; s < ST_COUNT; s++) {
@@ -229,9 +240,12 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     }
     static const bool want_overlap = getenv("ORBX_OVERLAP") && atoi(getenv("ORBX_OVERLAP")) != 0;
     const bool overlap = c->aux_stream && want_overlap && !pyramid_only;
-    if (es) es->chained = !overlap;
-    auto t0 = [&](int i, hipStream_t q) { if (es && (i == 0 || !es->chained)) (void)hipEventRecord(es->start[i], q); };
-    auto t1 = [&](int i, hipStream_t q) { if (es) (void)hipEventRecord(es->stop[i], q); };
+    const bool only_fast = c->stage_timing == 2;
+    if (es) { es->chained = !overlap && !only_fast; es->only_fast = only_fast; }
+    auto t0 = [&](int i, hipStream_t q) {
+        if (es && (only_fast ? i == ST_FAST : (i == 0 || !es->chained))) (void)hipEventRecord(es->start[i], q);
+    };
+    auto t1 = [&](int i, hipStream_t q) { if (es && (!only_fast || i == ST_FAST)) (void)hipEventRecord(es->stop[i], q); };
 
     t0(ST_PYR0, s);
     launch_pyr_level0(d_imgs, stride, frame_stride, pyr, g, nframes, s);
@@ -836,7 +850,7 @@ int orbx_reset_stage_times(orbx_ctx* c)
 int orbx_set_stage_timing(orbx_ctx* c, int enable)
 {
     if (!c) return ORBX_ERR_INVALID;
-    c->stage_timing = enable != 0;
+    c->stage_timing = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
     return ORBX_OK;
 }
 

@@ -194,4 +194,4 @@ class ORBextractor:
         check(self._lib, self._ctx, self._lib.orbx_reset_stage_times(self._ctx))
 
     def set_stage_timing(self, enable):
-        check(self._lib, self._ctx, self._lib.orbx_set_stage_timing(self._ctx, 1 if enable else 0))
+        check(self._lib, self._ctx, self._lib.orbx_set_stage_timing(self._ctx, int(enable)))   # 2: only the FAST launch

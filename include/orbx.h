@@ -165,10 +165,10 @@ int orbx_match_windowed(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_t 
 int orbx_hamming_csr(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_t *t, int T,
                      const int32_t *cand_off, const int32_t *cand_idx, uint16_t *dist_out);
 
-/* Stereo row-band search + disparity + median cut:
- * Frame::PrepareStereoCandidates (include/Frame.h:217-251) and
- * Frame::ComputeStereoMatches_Undistorted(false) (src/Frame.cc:1262-1422)
- * without map-point priors.  Host buffers, one pair.
+/* Stereo row-band search + disparity + median cut of a Frame that is matched in one piece:
+ * Frame::PrepareStereoCandidates (include/Frame.h:217-251) followed by
+ * Frame::ComputeStereoMatches_Undistorted(false) (src/Frame.cc:1262-1422) on a Frame without
+ * map points.  Host buffers, one pair, any number of keypoints.
  * best_idx[i] = -1 if left keypoint i was skipped before the scan.
  * u_right/depth: -1 where there is no match.  *nmatched as returned there. */
 int orbx_stereo_match(orbx_ctx *ctx, const orbx_keypoint *kl, const uint32_t *dl, int nl,
@@ -183,6 +183,42 @@ int orbx_stereo_match_device(orbx_ctx *ctx, const orbx_keypoint *d_kl, const uin
                              int nbatch, int stride, int nrows, float mbf, float mb, float min_x,
                              int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
                              int32_t *d_nmatched);
+
+/* The delayed stereo matching of the reference's default build (DELAYED_STEREO_MATCHING,
+ * include/Frame.h:38-40), where a Frame is matched in several calls:
+ *   Frame::ComputeStereoMatches_Undistorted(isOnline)  src/Frame.cc:1262-1422
+ *   Frame::ComputeStereoMatch_OnePoint(iL, thOrbDist, minD, maxD)  src/Frame.cc:1175-1260
+ * The Frame's members live in caller arrays of nl entries that this call updates exactly where
+ * the reference writes them (in/out):
+ *   u_right, depth  mvuRight / mvDepth, -1 after PrepareStereoCandidates (include/Frame.h:220-221);
+ *   listed_dist     mvDistIdx as an array: the Hamming distance of a left keypoint that holds a
+ *                   stereo match (:1393, :1253), -1 otherwise; -1 everywhere after Prepare;
+ *   best_idx, best_dist  result of the scan for the keypoints of this call (best_idx = -1: left
+ *                   before the scan, the reference's `continue` / `return false`).
+ * active[iL] != 0 selects the left keypoints this call works on (NULL: all); the caller derives it
+ * from mvpMapPoints / mvStereoMatched as :1283-1297 and :1182 do, and sets mvStereoMatched for
+ * them (:1304, :1187).  min_d / max_d: disparity window per left keypoint (NULL: 0 and mbf / mb);
+ * the caller narrows it from the map point's depth as :1325-1338 do.  th_orb_dist: 75 in
+ * ComputeStereoMatches_Undistorted (:1264), the argument of _OnePoint.  min_x: mnMinX (:1344), 0 for
+ * _OnePoint (:1207).  median_cut != 0 is the !isOnline tail (:1400-1419): every listed keypoint,
+ * of this call or an earlier one, whose distance is not below 2.1 x the median loses u_right and
+ * depth.  *nmatched: keypoints of this call that reached the scan, minus the cut ones (:1397,
+ * :1416) -- for _OnePoint the reference's return value is (listed_dist[iL] >= 0) afterwards. */
+int orbx_stereo_match_ex(orbx_ctx *ctx, const orbx_keypoint *kl, const uint32_t *dl, int nl,
+                         const orbx_keypoint *kr, const uint32_t *dr, int nr,
+                         int nrows, float mbf, float mb, float min_x,
+                         const uint8_t *active, const float *min_d, const float *max_d,
+                         int th_orb_dist, int median_cut, int32_t *listed_dist,
+                         int32_t *best_idx, int32_t *best_dist, float *u_right, float *depth, int *nmatched);
+/* The same, device-resident, asynchronous, batched over pairs; the per-keypoint arrays are
+ * [nbatch][stride]. */
+int orbx_stereo_match_ex_device(orbx_ctx *ctx, const orbx_keypoint *d_kl, const uint32_t *d_dl, const int32_t *d_nl,
+                                const orbx_keypoint *d_kr, const uint32_t *d_dr, const int32_t *d_nr,
+                                int nbatch, int stride, int nrows, float mbf, float mb, float min_x,
+                                const uint8_t *d_active, const float *d_min_d, const float *d_max_d,
+                                int th_orb_dist, int median_cut, int32_t *d_listed_dist,
+                                int32_t *d_best_idx, int32_t *d_best_dist, float *d_u_right, float *d_depth,
+                                int32_t *d_nmatched);
 
 /* Classic stereo matching with sub-pixel refinement: Frame::ComputeStereoMatches,
  * src/Frame.cc:984-1173 -- row-band Hamming search, 11x11 SAD sliding window on pyramid level

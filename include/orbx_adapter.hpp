@@ -12,6 +12,7 @@
 #include <opencv2/features2d/features2d.hpp>
 
 #include <cassert>
+#include <cstdlib>
 #include <cstring>
 #include <list>
 #include <vector>
@@ -26,8 +27,17 @@ class ORBextractor {
 public:
     enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
 
+    // The reference's constructor has no device argument: extractors created afterwards run on the
+    // GPU named by SetDevice(), initially the one in the environment variable ORBX_DEVICE (default 0).
+    static int& Device()
+    {
+        static int dev = std::getenv("ORBX_DEVICE") ? std::atoi(std::getenv("ORBX_DEVICE")) : 0;
+        return dev;
+    }
+    static void SetDevice(int device) { Device() = device; }
+
     ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST)
-        : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, /*device=*/0)
+        : impl_(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, Device())
     {
         mvImagePyramid.resize(nlevels);
     }
@@ -65,9 +75,10 @@ public:
     std::vector<float> inline GetScaleSigmaSquares() { return impl_.GetScaleSigmaSquares(); }
     std::vector<float> inline GetInverseScaleSigmaSquares() { return impl_.GetInverseScaleSigmaSquares(); }
 
-    // Host-readable, un-blurred level images of the last call (views into the
-    // library's host copy; 19 REFLECT_101 border pixels around each, so a
-    // cv::Mat::adjustROI by up to 19 is valid like in the reference).
+    // Host-readable, un-blurred level images of the last call: each is a region of interest inside
+    // a matrix that also holds its 19 REFLECT_101 border pixels, as in the reference
+    // (src/ORBextractor.cc:1198-1200), so locateROI / adjustROI by up to 19 and a copyMakeBorder
+    // without BORDER_ISOLATED see the stored border.
     std::vector<cv::Mat> mvImagePyramid;
 
     void ComputePyramid(cv::Mat image)
@@ -81,7 +92,9 @@ private:
     {
         for (size_t l = 0; l < mvImagePyramid.size(); l++) {
             const orbx::ImageView& v = impl_.mvImagePyramid[l];
-            mvImagePyramid[l] = cv::Mat(v.rows, v.cols, CV_8UC1, const_cast<uint8_t*>(v.data), v.step);
+            const int B = 19;    // EDGE_THRESHOLD, src/ORBextractor.cc:72; the library stores at least that much
+            cv::Mat whole(v.rows + 2 * B, v.cols + 2 * B, CV_8UC1, const_cast<uint8_t*>(v.data) - (size_t)B * v.step - B, v.step);
+            mvImagePyramid[l] = whole(cv::Rect(B, B, v.cols, v.rows));
         }
     }
     orbx::ORBextractor impl_;

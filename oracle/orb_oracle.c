@@ -59,6 +59,7 @@ struct oo_extractor {
     uint8_t *plane[OO_MAX_LEVELS];
     int lw[OO_MAX_LEVELS], lh[OO_MAX_LEVELS];
     int level_counts[OO_MAX_LEVELS];
+    int trig_mode; /* OO_TRIG_LIBM (the reference's calls) or OO_TRIG_ROUNDED */
 };
 
 /* src/ORBextractor.cc:967-1026 */
@@ -71,6 +72,7 @@ oo_extractor *oo_create(int nfeatures, float scaleFactor, int nlevels, int iniTh
     ex->nlevels = nlevels;
     ex->iniTh = iniThFAST;
     ex->minTh = minThFAST;
+    ex->trig_mode = OO_TRIG_LIBM;
 
     ex->scale[0] = 1.0f;
     ex->sigma2[0] = 1.0f;
@@ -988,11 +990,21 @@ void oo_gaussian_blur7(const uint8_t *src, int w, int h, int sstride, uint8_t *d
 /* ------------------------------------------------------------------------- */
 /* computeOrbDescriptor src/ORBextractor.cc:103-150                           */
 /* ------------------------------------------------------------------------- */
-void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32])
+void oo_set_trig_mode(oo_extractor *ex, int mode) { ex->trig_mode = mode; }
+
+/* The reference writes cos(angle) / sin(angle) on a float under `using namespace std`
+ * (src/ORBextractor.cc:64-65, :108-109): the float overloads, i.e. libm's cosf / sinf, whose
+ * last bit depends on the libm in use (they are not correctly rounded).  OO_TRIG_LIBM calls this
+ * host's cosf / sinf as the reference does; OO_TRIG_ROUNDED takes the correctly rounded values
+ * (double cos / sin rounded to float), the platform-independent formulation the GPU kernel
+ * evaluates.  See the count of differing angles in orb_oracle.h. */
+void oo_orb_descriptor_mode(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32], int trig_mode)
 {
     const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
     float angle = angle_deg * factorPI;
-    float a = (float)cos((double)angle), b = (float)sin((double)angle);
+    float a, b;
+    if (trig_mode == OO_TRIG_LIBM) { a = cosf(angle); b = sinf(angle); }
+    else { a = (float)cos((double)angle); b = (float)sin((double)angle); }
     const int *pat = g_pattern;
     for (int i = 0; i < 32; ++i, pat += 32) {
         int val = 0;
@@ -1006,6 +1018,33 @@ void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8
         }
         desc[i] = (uint8_t)val;
     }
+}
+
+void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32])
+{
+    oo_orb_descriptor_mode(center, stride, angle_deg, desc, OO_TRIG_LIBM);
+}
+
+/* number of float angles in [0, 360) degrees (every value cv::fastAtan2 can return lies there)
+ * whose libm cosf / sinf differ from the correctly rounded value; counts[0] = cos, counts[1] = sin.
+ * Walks the floats first, first + step, ... below 360.0f (first = 0, step = 1: all 1 135 869 952). */
+void oo_count_trig_differences(uint32_t first, uint32_t step, uint64_t counts[2], uint64_t *tested)
+{
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    const uint32_t end = 0x43B40000u; /* bit pattern of 360.0f */
+    uint64_t c = 0, s = 0, n = 0;
+    if (step == 0) step = 1;
+    for (uint64_t u = first; u < end; u += step) {
+        uint32_t bits = (uint32_t)u;
+        float deg;
+        memcpy(&deg, &bits, 4);
+        volatile float x = deg * factorPI;
+        const float xa = x;
+        c += cosf(xa) != (float)cos((double)xa);
+        s += sinf(xa) != (float)sin((double)xa);
+        n++;
+    }
+    counts[0] = c; counts[1] = s; *tested = n;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1054,7 +1093,7 @@ int oo_extract(oo_extractor *ex, const uint8_t *img, int w, int h, int stride,
             int m01, m10;
             oo_ic_moments(im + (size_t)cy * pitch + cx, pitch, ex->umax, &m01, &m10);
             kp->angle = oo_fast_atan2((float)m01, (float)m10);
-            oo_orb_descriptor(blur + (size_t)cy * cols + cx, cols, kp->angle, desc + (size_t)(total + k) * 32);
+            oo_orb_descriptor_mode(blur + (size_t)cy * cols + cx, cols, kp->angle, desc + (size_t)(total + k) * 32, ex->trig_mode);
             if (level != 0) { /* :1179-1186 */
                 float scale = ex->scale[level];
                 kp->x *= scale;
@@ -1239,6 +1278,173 @@ int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
     }
     free(v);
     return nmatched;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Delayed stereo matching of the default build (DELAYED_STEREO_MATCHING,       */
+/* include/Frame.h:40): the Frame members it reads and writes are the arrays    */
+/* of oo_stereo_state.                                                         */
+/* ------------------------------------------------------------------------- */
+typedef struct { int *start, *idx; } oo_rowtab;
+
+/* mvRowIndices, include/Frame.h:228-246 (order inside a row = ascending iR) */
+static void rowtab_build(oo_rowtab *rt, const oo_keypoint *kr, int nr, const float *scale_factors, int nrows)
+{
+    rt->start = (int *)calloc((size_t)nrows + 1, sizeof(int));
+    for (int pass = 0; pass < 2; pass++) {
+        int *fill = NULL;
+        if (pass == 1) {
+            for (int y = 0; y < nrows; y++) rt->start[y + 1] += rt->start[y];
+            rt->idx = (int *)malloc(sizeof(int) * (rt->start[nrows] > 0 ? rt->start[nrows] : 1));
+            fill = (int *)malloc(sizeof(int) * ((size_t)nrows + 1));
+            memcpy(fill, rt->start, sizeof(int) * ((size_t)nrows + 1));
+        }
+        for (int iR = 0; iR < nr; iR++) {
+            const float kpY = kr[iR].y;
+            const float r = 2.0f * scale_factors[kr[iR].octave];
+            const int maxr = (int)fminf((float)(nrows - 1), ceilf(kpY + r));
+            const int minr = (int)fmaxf(0.0f, floorf(kpY - r));
+            for (int yi = minr; yi <= maxr; yi++) {
+                if (pass == 0) rt->start[yi + 1]++;
+                else rt->idx[fill[yi]++] = iR;
+            }
+        }
+        free(fill);
+    }
+}
+static void rowtab_free(oo_rowtab *rt) { free(rt->start); free(rt->idx); }
+
+/* Frame::PrepareStereoCandidates, include/Frame.h:217-251: the state a Frame starts from */
+void oo_stereo_prepare(oo_stereo_state *st, int nl)
+{
+    for (int i = 0; i < nl; i++) {
+        st->u_right[i] = -1.0f;
+        st->depth[i] = -1.0f;
+        st->stereo_matched[i] = 0;
+    }
+    st->n_dist_idx = 0;
+}
+
+/* The part the two reference functions share word for word: src/Frame.cc:1189-1257
+ * (ComputeStereoMatch_OnePoint) and :1306-1395 (loop body of ComputeStereoMatches_Undistorted).
+ * min_u_limit is 0 in the former (:1207) and mnMinX in the latter (:1344).
+ * Returns 0 if the keypoint leaves before the scan (return false / continue), 1 if it was scanned
+ * without an accepted disparity, 2 if a disparity was stored. */
+static int stereo_one_left(const oo_keypoint *kl, const uint32_t *dl, int iL, const oo_keypoint *kr, const uint32_t *dr,
+                           const oo_rowtab *rt, int nrows, int thOrbDist, float minD, float maxD, float mbf,
+                           float min_u_limit, oo_stereo_state *st, int32_t *best_idx, int32_t *best_dist)
+{
+    const int levelL = kl[iL].octave;
+    const float vL = kl[iL].y, uL = kl[iL].x;
+    if (vL < 0 || vL > nrows - 1) return 0;
+    const int row = (int)vL;
+    if (rt->start[row + 1] == rt->start[row]) return 0;
+    const float minU = uL - maxD, maxU = uL - minD;
+    if (maxU < min_u_limit) return 0;
+    int bestDist = 100; /* ORBmatcher::TH_HIGH */
+    int bestIdxR = 0;
+    for (int k = rt->start[row]; k < rt->start[row + 1]; k++) {
+        const int iR = rt->idx[k];
+        if (kr[iR].octave < levelL - 1 || kr[iR].octave > levelL + 1) continue;
+        const float uR = kr[iR].x;
+        if (uR >= minU && uR <= maxU) {
+            const int dist = oo_hamming(dl + 8 * (size_t)iL, dr + 8 * (size_t)iR);
+            if (dist < bestDist) { bestDist = dist; bestIdxR = iR; }
+        }
+    }
+    if (best_idx) best_idx[iL] = bestIdxR;
+    if (best_dist) best_dist[iL] = bestDist;
+    if (bestDist < thOrbDist) {
+        float bestuR = kr[bestIdxR].x;
+        float disparity = uL - bestuR;
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01f;
+                bestuR = (float)(uL - 0.01);
+            }
+            st->depth[iL] = mbf / disparity;
+            st->u_right[iL] = bestuR;
+            st->dist_idx_dist[st->n_dist_idx] = bestDist;
+            st->dist_idx_il[st->n_dist_idx] = iL;
+            st->n_dist_idx++;
+            return 2;
+        }
+    }
+    return 1;
+}
+
+/* Frame::ComputeStereoMatches_Undistorted(isOnline), src/Frame.cc:1262-1422, as compiled with
+ * DELAYED_STEREO_MATCHING.  has_mappoint[iL] = (mvpMapPoints[iL] != NULL), NULL = no map points;
+ * prior_disp[iL] = mbf / Pc.z of a map point that is not bad and lies in front of the camera
+ * (:1325-1334), <= 0 where there is none; disparity_thres = DISPARITY_THRES (include/Frame.h:47).
+ * best_idx / best_dist (may be NULL) are written for scanned keypoints only.
+ * With an empty mvDistIdx the reference reads element 0 of an empty vector (:1403); the cut is
+ * skipped here. */
+int oo_stereo_undistorted(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                          const oo_keypoint *kr, const uint32_t *dr, int nr,
+                          const float *scale_factors, int nrows, float mbf, float mb, float minX,
+                          float disparity_thres, const uint8_t *has_mappoint, const float *prior_disp,
+                          int is_online, oo_stereo_state *st, int32_t *best_idx, int32_t *best_dist)
+{
+    const int thOrbDist = (100 + 50) / 2;
+    oo_rowtab rt;
+    rowtab_build(&rt, kr, nr, scale_factors, nrows);
+    const float minZ = mb;
+    int nmatched = 0;
+    for (int iL = 0; iL < nl; iL++) {
+        const int mp = has_mappoint ? has_mappoint[iL] : 0;
+        if (is_online) {
+            if (!mp || st->stereo_matched[iL]) continue;
+        } else {
+            if (st->stereo_matched[iL]) continue;
+        }
+        float minD = 0;
+        float maxD = mbf / minZ;
+        st->stereo_matched[iL] = 1;
+        if (mp && prior_disp && prior_disp[iL] > 0) {
+            const float disp = prior_disp[iL];
+            minD = fmaxf(disp - disparity_thres, 0.0f);
+            maxD = fminf(disp + disparity_thres, mbf / mb);
+        }
+        if (stereo_one_left(kl, dl, iL, kr, dr, &rt, nrows, thOrbDist, minD, maxD, mbf, minX, st, best_idx, best_dist) == 0)
+            continue;
+        nmatched++;
+    }
+    if (!is_online && st->n_dist_idx > 0) {
+        const int nv = st->n_dist_idx;
+        distidx *v = (distidx *)malloc(sizeof(distidx) * nv);
+        for (int i = 0; i < nv; i++) { v[i].dist = st->dist_idx_dist[i]; v[i].idx = st->dist_idx_il[i]; }
+        qsort(v, nv, sizeof(distidx), distidx_cmp);
+        for (int i = 0; i < nv; i++) { st->dist_idx_dist[i] = v[i].dist; st->dist_idx_il[i] = v[i].idx; }
+        const float median = (float)v[nv / 2].dist;
+        const float thDist = 1.5f * 1.4f * median;
+        for (int i = nv - 1; i >= 0; i--) {
+            if ((float)v[i].dist < thDist) break;
+            st->u_right[v[i].idx] = -1;
+            st->depth[v[i].idx] = -1;
+            nmatched--;
+        }
+        free(v);
+    }
+    rowtab_free(&rt);
+    return nmatched;
+}
+
+/* Frame::ComputeStereoMatch_OnePoint, src/Frame.cc:1175-1260. has_mappoint as above. */
+int oo_stereo_one_point(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                        const oo_keypoint *kr, const uint32_t *dr, int nr,
+                        const float *scale_factors, int nrows, float mbf,
+                        const uint8_t *has_mappoint, int iL, int thOrbDist, float minD, float maxD,
+                        oo_stereo_state *st, int32_t *best_idx, int32_t *best_dist)
+{
+    if (iL < 0 || iL >= nl) return 0;
+    if (!has_mappoint || !has_mappoint[iL] || st->stereo_matched[iL]) return 0;
+    st->stereo_matched[iL] = 1;
+    oo_rowtab rt;
+    rowtab_build(&rt, kr, nr, scale_factors, nrows);
+    const int r = stereo_one_left(kl, dl, iL, kr, dr, &rt, nrows, thOrbDist, minD, maxD, mbf, 0.0f, st, best_idx, best_dist);
+    rowtab_free(&rt);
+    return r == 2;
 }
 
 /* src/Frame.cc:984-1173 */

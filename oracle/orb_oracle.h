@@ -97,8 +97,24 @@ float oo_fast_atan2(float y, float x);
 void oo_gaussian_blur7(const uint8_t *src_origin, int w, int h, int sstride,
                        uint8_t *dst, int dstride);
 
-/* computeOrbDescriptor, src/ORBextractor.cc:104-150 */
+/* computeOrbDescriptor, src/ORBextractor.cc:104-150.
+ * The reference takes cos / sin of a float angle through the float overloads (cosf / sinf of the
+ * libm it is linked with, :108-109), which are not correctly rounded and differ between libm
+ * versions in the last bit.  OO_TRIG_LIBM calls this host's cosf / sinf, as the reference does
+ * (the default of an extractor and of oo_orb_descriptor); OO_TRIG_ROUNDED uses the correctly
+ * rounded values, the platform-independent formulation the GPU kernel evaluates.
+ * Measured with oo_count_trig_differences on glibc 2.35 (x86-64) over all 1 135 869 952 float
+ * angles in [0, 360): cosf differs from the correctly rounded value for 483 807 of them, sinf for
+ * 1 001 902 (always by one unit in the last place).  A differing a or b changes a descriptor only
+ * when a rotated coordinate lies within that unit of a rounding boundary: tests measure the share
+ * of descriptors that differ between the two modes (none on the committed frames; the parity
+ * budget is 0.1 %).  PARITY UNPINNED like the rest of this file. */
+#define OO_TRIG_LIBM 0
+#define OO_TRIG_ROUNDED 1
+void oo_set_trig_mode(oo_extractor *ex, int mode);
 void oo_orb_descriptor(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32]);
+void oo_orb_descriptor_mode(const uint8_t *center, int stride, float angle_deg, uint8_t desc[32], int trig_mode);
+void oo_count_trig_differences(uint32_t first, uint32_t step, uint64_t counts[2], uint64_t *tested);
 
 /* ORBextractor::operator(), src/ORBextractor.cc:1127-1190. Returns the number
  * of keypoints (<= cap) or -1 if cap is too small. literal selects the literal
@@ -139,6 +155,35 @@ void oo_stereo_search(const oo_keypoint *kl, const uint32_t *dl, int nl,
 int oo_stereo_finish(const oo_keypoint *kl, int nl, const oo_keypoint *kr,
                      const int32_t *best_idx, const int32_t *best_dist,
                      float mbf, float minD, float maxD, float *u_right, float *depth);
+
+/* The Frame members the delayed stereo matching of the default build reads and writes
+ * (DELAYED_STEREO_MATCHING, include/Frame.h:40): mvuRight, mvDepth, mvStereoMatched and mvDistIdx
+ * (pairs (bestDist, iL) in push_back order; sorted in place by the offline call, src/Frame.cc:1402).
+ * All arrays are owned by the caller and hold nl entries. */
+typedef struct {
+    float *u_right, *depth;
+    uint8_t *stereo_matched;
+    int32_t *dist_idx_dist, *dist_idx_il;
+    int32_t n_dist_idx;
+} oo_stereo_state;
+/* Frame::PrepareStereoCandidates, include/Frame.h:217-251 (state part; the row table is rebuilt
+ * from the right keypoints by the calls below) */
+void oo_stereo_prepare(oo_stereo_state *st, int nl);
+/* Frame::ComputeStereoMatches_Undistorted(isOnline), src/Frame.cc:1262-1422: online = only
+ * keypoints with a map point, disparity window narrowed to prior +- DISPARITY_THRES, no median cut;
+ * offline = every keypoint not matched yet, then the cut at 2.1 x median over all of mvDistIdx.
+ * Returns nmatched as the reference does (scanned keypoints minus cut ones). */
+int oo_stereo_undistorted(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                          const oo_keypoint *kr, const uint32_t *dr, int nr,
+                          const float *scale_factors, int nrows, float mbf, float mb, float minX,
+                          float disparity_thres, const uint8_t *has_mappoint, const float *prior_disp,
+                          int is_online, oo_stereo_state *st, int32_t *best_idx, int32_t *best_dist);
+/* Frame::ComputeStereoMatch_OnePoint, src/Frame.cc:1175-1260; returns 1 where it returns true */
+int oo_stereo_one_point(const oo_keypoint *kl, const uint32_t *dl, int nl,
+                        const oo_keypoint *kr, const uint32_t *dr, int nr,
+                        const float *scale_factors, int nrows, float mbf,
+                        const uint8_t *has_mappoint, int iL, int thOrbDist, float minD, float maxD,
+                        oo_stereo_state *st, int32_t *best_idx, int32_t *best_dist);
 
 /* Frame::ComputeStereoMatches, src/Frame.cc:984-1173 (the classic variant): row-band Hamming
  * search, then 11x11 SAD sliding-window refinement on pyramid level kpL.octave of the two

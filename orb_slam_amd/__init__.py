@@ -9,7 +9,7 @@ library and a gfx950 device.
 from ._lib import OrbxError, KP_DTYPE, load_library, library_path  # noqa: F401
 from .extractor import ORBextractor  # noqa: F401
 from .matcher import ORBmatcher  # noqa: F401
-from .frame import Frame, CameraModel  # noqa: F401
+from .frame import Frame, CameraModel, StereoFrame  # noqa: F401
 from .detection_io import ExportToYML, KeyPointLog  # noqa: F401
 
-__all__ = ["ORBextractor", "ORBmatcher", "Frame", "CameraModel", "ExportToYML", "KeyPointLog", "OrbxError", "KP_DTYPE", "load_library", "library_path"]
+__all__ = ["ORBextractor", "ORBmatcher", "Frame", "CameraModel", "StereoFrame", "ExportToYML", "KeyPointLog", "OrbxError", "KP_DTYPE", "load_library", "library_path"]

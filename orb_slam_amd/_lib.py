@@ -66,6 +66,10 @@ SIGNATURES = {
                                      _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp]),
+    "orbx_stereo_match_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _i, _i, _vp,
+                                  _vp, _vp, _vp, _vp, _ip]),
+    "orbx_stereo_match_ex_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp,
+                                         _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_detection_write_yaml": (_i, [C.c_char_p, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _i, _vp, _vp, _i, _i]),
     "orbx_detection_read_yaml": (_i, [C.c_char_p, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "orbx_io_last_error": (C.c_char_p, []),

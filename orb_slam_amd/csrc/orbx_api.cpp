@@ -84,7 +84,7 @@ struct orbx_ctx {
     DevBuf in, out_kps, out_desc, out_n;
     // scratch for matching
     DevBuf partial, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
-    DevBuf grid_start, grid_list, gq[12];
+    DevBuf grid_start, grid_list, gq[12], stereo_listed;
 
     int last_nframes = 0;
     bool have_pyramid = false, have_features = false;
@@ -497,7 +497,8 @@ void orbx_destroy(orbx_ctx* c)
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
-                      &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11]};
+                      &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],
+                      &c->stereo_listed};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
@@ -623,12 +624,17 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
                        cap_per_frame, hn, false);
         if (rc != ORBX_OK) return rc;
         HIPCHECK(c, finish(c));
+        // every frame is delivered (the first cap_per_frame keypoints of one that overflows) before
+        // the overflow is reported, as on the copy path below
+        bool overflow = false;
         for (int f = 0; f < nframes; f++) {
             n_out[f] = hn[f];
-            if (hn[f] > cap_per_frame) return fail(c, ORBX_ERR_CAPACITY, "cap_per_frame smaller than the number of keypoints");
-            std::memcpy(kps + (size_t)f * cap_per_frame, base + o_k + f * kb, (size_t)hn[f] * sizeof(orbx_keypoint));
-            std::memcpy(desc + (size_t)f * db, base + o_d + f * db, (size_t)hn[f] * 32);
+            const size_t m = (size_t)std::min(hn[f], cap_per_frame);
+            overflow = overflow || hn[f] > cap_per_frame;
+            std::memcpy(kps + (size_t)f * cap_per_frame, base + o_k + f * kb, m * sizeof(orbx_keypoint));
+            std::memcpy(desc + (size_t)f * db, base + o_d + f * db, m * 32);
         }
+        if (overflow) return fail(c, ORBX_ERR_CAPACITY, "cap_per_frame smaller than the number of keypoints");
         return ORBX_OK;
     }
     // uploads frames [f_lo, f_hi) on stream q; frames that lie back to back in host memory (one array
@@ -994,40 +1000,85 @@ int orbx_hamming_csr(orbx_ctx* c, const uint32_t* q, int Q, const uint32_t* t, i
     return ORBX_OK;
 }
 
+// shared by the stereo entry points: argument checks + the two launches
+static int stereo_launch(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                         const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr, int nbatch, int stride,
+                         int nrows, float mbf, float mb, float min_x, const uint8_t* d_active, const float* d_min_d,
+                         const float* d_max_d, int th_orb_dist, int median_cut, int init_outputs, int32_t* d_listed,
+                         int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth, int32_t* d_nmatched)
+{
+    if (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist || !d_u_right || !d_depth || !d_nmatched)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (nbatch < 1 || nbatch > 65535 || stride < 1 || nrows < 1) return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (stride >= (1 << 22)) return fail(c, ORBX_ERR_UNSUPPORTED, "2^22 keypoints per image or more");
+    if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
+    if (th_orb_dist < 0 || th_orb_dist > 256) return fail(c, ORBX_ERR_INVALID, "th_orb_dist must be in [0, 256]");
+    if (median_cut && !d_listed) return fail(c, ORBX_ERR_INVALID, "the median cut needs the listed-distance array");
+    HIPCHECK(c, hipSetDevice(c->device));
+    StereoLaunch L;
+    L.d_kl = d_kl; L.d_kr = d_kr; L.d_dl = d_dl; L.d_dr = d_dr; L.d_nl = d_nl; L.d_nr = d_nr;
+    L.d_active = d_active; L.d_min_d = d_min_d; L.d_max_d = d_max_d; L.d_listed = d_listed;
+    L.d_best_idx = d_best_idx; L.d_best_dist = d_best_dist; L.d_u_right = d_u_right; L.d_depth = d_depth;
+    L.d_nmatched = d_nmatched;
+    L.nbatch = nbatch; L.stride = stride; L.nrows = nrows; L.th_orb_dist = th_orb_dist;
+    L.init_outputs = init_outputs; L.median_cut = median_cut;
+    L.mbf = mbf; L.mb = mb; L.min_x = min_x;
+    launch_stereo_match(L, c->p.scale, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
 int orbx_stereo_match_device(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
                              const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr, int nbatch, int stride,
                              int nrows, float mbf, float mb, float min_x, int32_t* d_best_idx, int32_t* d_best_dist,
                              float* d_u_right, float* d_depth, int32_t* d_nmatched)
 {
     if (!c) return ORBX_ERR_INVALID;
-    if (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist || !d_u_right || !d_depth || !d_nmatched)
-        return fail(c, ORBX_ERR_INVALID, "null buffer");
-    if (nbatch < 1 || stride < 1 || nrows < 1 || nrows > 32767) return fail(c, ORBX_ERR_INVALID, "bad sizes");
-    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per image");
-    if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
+    if (nbatch < 1 || nbatch > 65535 || stride < 1) return fail(c, ORBX_ERR_INVALID, "bad sizes");
     HIPCHECK(c, hipSetDevice(c->device));
-    launch_stereo_match(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, c->p.scale, mbf, mb, min_x,
-                        d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, c->stream);
-    HIPCHECK(c, hipGetLastError());
-    return ORBX_OK;
+    // mvDistIdx of a Frame that is matched in one piece: scratch of the context
+    const size_t need = (size_t)nbatch * stride * 4;
+    if (need > c->stereo_listed.bytes) {
+        HIPCHECK(c, finish(c));
+        HIPCHECK(c, c->stereo_listed.ensure(need));
+    }
+    return stereo_launch(c, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, mbf, mb, min_x, nullptr, nullptr,
+                         nullptr, 75, 1, 1, c->stereo_listed.as<int32_t>(), d_best_idx, d_best_dist, d_u_right, d_depth,
+                         d_nmatched);
 }
 
-int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, int nl, const orbx_keypoint* kr,
-                      const uint32_t* dr, int nr, int nrows, float mbf, float mb, float min_x, int32_t* best_idx,
-                      int32_t* best_dist, float* u_right, float* depth, int* nmatched)
+int orbx_stereo_match_ex_device(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
+                                const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr, int nbatch,
+                                int stride, int nrows, float mbf, float mb, float min_x, const uint8_t* d_active,
+                                const float* d_min_d, const float* d_max_d, int th_orb_dist, int median_cut,
+                                int32_t* d_listed_dist, int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right,
+                                float* d_depth, int32_t* d_nmatched)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (!d_listed_dist) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    return stereo_launch(c, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, mbf, mb, min_x, d_active, d_min_d,
+                         d_max_d, th_orb_dist, median_cut, 0, d_listed_dist, d_best_idx, d_best_dist, d_u_right, d_depth,
+                         d_nmatched);
+}
+
+// one pair from host buffers; ex: in/out state arrays as orbx_stereo_match_ex documents them
+static int stereo_host(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, int nl, const orbx_keypoint* kr,
+                       const uint32_t* dr, int nr, int nrows, float mbf, float mb, float min_x, bool ex,
+                       const uint8_t* active, const float* min_d, const float* max_d, int th_orb_dist, int median_cut,
+                       int32_t* listed, int32_t* best_idx, int32_t* best_dist, float* u_right, float* depth, int* nmatched)
 {
     if (!c || !nmatched) return ORBX_ERR_INVALID;
     *nmatched = 0;
     if (nl < 0 || nr < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
     if (nl == 0) return ORBX_OK;
-    if (!kl || !dl || !best_idx || !best_dist || !u_right || !depth || (nr > 0 && (!kr || !dr)))
+    if (!kl || !dl || !best_idx || !best_dist || !u_right || !depth || (nr > 0 && (!kr || !dr)) || (ex && !listed))
         return fail(c, ORBX_ERR_INVALID, "null buffer");
     for (int i = 0; i < nr; i++)
         if (kr[i].octave < 0 || kr[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "right keypoint octave out of range");
     const int stride = nl > nr ? nl : nr;
     HIPCHECK(c, hipSetDevice(c->device));
     HIPCHECK(c, finish(c));
-    const size_t S = (size_t)stride;
+    const size_t S = (size_t)stride, NL = (size_t)nl;
     HIPCHECK(c, c->m0.ensure(S * sizeof(orbx_keypoint)));
     HIPCHECK(c, c->m1.ensure(S * 32));
     HIPCHECK(c, c->m2.ensure(S * sizeof(orbx_keypoint)));
@@ -1037,28 +1088,70 @@ int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, 
     HIPCHECK(c, c->m6.ensure(S * 4));
     HIPCHECK(c, c->m7.ensure(S * 4));
     HIPCHECK(c, c->m8.ensure(S * 4));
+    HIPCHECK(c, c->m9.ensure(S * 4 * 3 + S));        // listed | min_d | max_d | active
+    HIPCHECK(c, c->stereo_listed.ensure(S * 4));
     int32_t counts[3] = {nl, nr, 0};
-    HIPCHECK(c, h2d(c, c->m0.p, kl, (size_t)nl * sizeof(orbx_keypoint)));
-    HIPCHECK(c, h2d(c, c->m1.p, dl, (size_t)nl * 32));
+    HIPCHECK(c, h2d(c, c->m0.p, kl, NL * sizeof(orbx_keypoint)));
+    HIPCHECK(c, h2d(c, c->m1.p, dl, NL * 32));
     if (nr > 0) {
         HIPCHECK(c, h2d(c, c->m2.p, kr, (size_t)nr * sizeof(orbx_keypoint)));
         HIPCHECK(c, h2d(c, c->m3.p, dr, (size_t)nr * 32));
     }
     HIPCHECK(c, h2d(c, c->m4.p, counts, sizeof(counts)));
-    int rc = orbx_stereo_match_device(c, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
+    int32_t* d_listed = c->m9.as<int32_t>();
+    float* d_min = reinterpret_cast<float*>(d_listed + S);
+    float* d_max = d_min + S;
+    uint8_t* d_act = reinterpret_cast<uint8_t*>(d_max + S);
+    int rc;
+    if (ex) {
+        // in/out state of the Frame: what the kernels only touch where the reference writes
+        HIPCHECK(c, h2d(c, d_listed, listed, NL * 4));
+        HIPCHECK(c, h2d(c, c->m7.p, u_right, NL * 4));
+        HIPCHECK(c, h2d(c, c->m8.p, depth, NL * 4));
+        HIPCHECK(c, h2d(c, c->m5.p, best_idx, NL * 4));
+        HIPCHECK(c, h2d(c, c->m6.p, best_dist, NL * 4));
+        if (active) HIPCHECK(c, h2d(c, d_act, active, NL));
+        if (min_d) HIPCHECK(c, h2d(c, d_min, min_d, NL * 4));
+        if (max_d) HIPCHECK(c, h2d(c, d_max, max_d, NL * 4));
+        rc = orbx_stereo_match_ex_device(c, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
+                                         c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1,
+                                         stride, nrows, mbf, mb, min_x, active ? d_act : nullptr, min_d ? d_min : nullptr,
+                                         max_d ? d_max : nullptr, th_orb_dist, median_cut, d_listed, c->m5.as<int32_t>(),
+                                         c->m6.as<int32_t>(), c->m7.as<float>(), c->m8.as<float>(), c->m4.as<int32_t>() + 2);
+    } else {
+        rc = orbx_stereo_match_device(c, c->m0.as<orbx_keypoint>(), c->m1.as<uint32_t>(), c->m4.as<int32_t>(),
                                       c->m2.as<orbx_keypoint>(), c->m3.as<uint32_t>(), c->m4.as<int32_t>() + 1, 1, stride,
                                       nrows, mbf, mb, min_x, c->m5.as<int32_t>(), c->m6.as<int32_t>(), c->m7.as<float>(),
                                       c->m8.as<float>(), c->m4.as<int32_t>() + 2);
+    }
     if (rc != ORBX_OK) return rc;
     int32_t nm = 0;
-    HIPCHECK(c, d2h(c, best_idx, c->m5.p, (size_t)nl * 4));
-    HIPCHECK(c, d2h(c, best_dist, c->m6.p, (size_t)nl * 4));
-    HIPCHECK(c, d2h(c, u_right, c->m7.p, (size_t)nl * 4));
-    HIPCHECK(c, d2h(c, depth, c->m8.p, (size_t)nl * 4));
+    HIPCHECK(c, d2h(c, best_idx, c->m5.p, NL * 4));
+    HIPCHECK(c, d2h(c, best_dist, c->m6.p, NL * 4));
+    HIPCHECK(c, d2h(c, u_right, c->m7.p, NL * 4));
+    HIPCHECK(c, d2h(c, depth, c->m8.p, NL * 4));
+    if (ex) HIPCHECK(c, d2h(c, listed, d_listed, NL * 4));
     HIPCHECK(c, d2h(c, &nm, c->m4.as<int32_t>() + 2, 4));
     HIPCHECK(c, finish(c));
     *nmatched = nm;
     return ORBX_OK;
+}
+
+int orbx_stereo_match(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, int nl, const orbx_keypoint* kr,
+                      const uint32_t* dr, int nr, int nrows, float mbf, float mb, float min_x, int32_t* best_idx,
+                      int32_t* best_dist, float* u_right, float* depth, int* nmatched)
+{
+    return stereo_host(c, kl, dl, nl, kr, dr, nr, nrows, mbf, mb, min_x, false, nullptr, nullptr, nullptr, 75, 1, nullptr,
+                       best_idx, best_dist, u_right, depth, nmatched);
+}
+
+int orbx_stereo_match_ex(orbx_ctx* c, const orbx_keypoint* kl, const uint32_t* dl, int nl, const orbx_keypoint* kr,
+                         const uint32_t* dr, int nr, int nrows, float mbf, float mb, float min_x, const uint8_t* active,
+                         const float* min_d, const float* max_d, int th_orb_dist, int median_cut, int32_t* listed_dist,
+                         int32_t* best_idx, int32_t* best_dist, float* u_right, float* depth, int* nmatched)
+{
+    return stereo_host(c, kl, dl, nl, kr, dr, nr, nrows, mbf, mb, min_x, true, active, min_d, max_d, th_orb_dist,
+                       median_cut, listed_dist, best_idx, best_dist, u_right, depth, nmatched);
 }
 
 int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* d_kl, const uint32_t* d_dl,

@@ -202,13 +202,14 @@ int keypoints_from(const Node& n, orbx_keypoint* out, int cap, int* count, const
     return ORBX_OK;
 }
 
-int descriptors_from(const Node& n, uint8_t* out, int count, const char* what)
+int descriptors_from(const Node& n, uint8_t* out, int cap, int count, const char* what)
 {
     if (!n.present) return io_fail(ORBX_ERR_INVALID, std::string("key missing: ") + what);
     if (count == 0) return ORBX_OK;    // an empty cv::Mat is written without data
     if (!n.is_matrix || n.dt != "u" || n.cols != 32 || n.rows != count || (long)n.numbers.size() != 32L * count)
         return io_fail(ORBX_ERR_INVALID, std::string(what) + ": expected a " + std::to_string(count) + " x 32 matrix of dt u");
     if (!out) return ORBX_OK;
+    if (count > cap) return io_fail(ORBX_ERR_CAPACITY, std::string(what) + ": buffer too small");
     for (long i = 0; i < 32L * count; i++) out[i] = (uint8_t)n.numbers[(size_t)i];
     return ORBX_OK;
 }
@@ -285,11 +286,11 @@ int orbx_detection_read_yaml(const char* path, double* mTimeStamp, orbx_keypoint
     if (!ts.present || ts.numbers.size() != 1) return io_fail(ORBX_ERR_INVALID, "mTimeStamp missing or not a number");
     int rc = keypoints_from(kl, keys, cap, n, "mvKeys");
     if (rc != ORBX_OK) return rc;
-    rc = descriptors_from(dl, desc, *n, "mDescriptors");
+    rc = descriptors_from(dl, desc, cap, *n, "mDescriptors");
     if (rc != ORBX_OK) return rc;
     rc = keypoints_from(kr, keys_right, cap_right, n_right, "mvKeysRight");
     if (rc != ORBX_OK) return rc;
-    rc = descriptors_from(dr, desc_right, *n_right, "mDescriptorsRight");
+    rc = descriptors_from(dr, desc_right, cap_right, *n_right, "mDescriptorsRight");
     if (rc != ORBX_OK) return rc;
     *mTimeStamp = ts.numbers[0];
     return ORBX_OK;

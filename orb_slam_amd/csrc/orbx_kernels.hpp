@@ -62,11 +62,21 @@ void launch_match_windowed(const uint32_t* d_q, int Q, const uint32_t* d_t, cons
                            int32_t* d_second_dist, int32_t* d_best_lvl, int32_t* d_second_lvl, hipStream_t s);
 void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
                         const int32_t* d_idx, uint16_t* d_out, hipStream_t s);
-void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
-                         const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
-                         int nbatch, int stride, int nrows, const float* scale8, float mbf, float mb, float min_x,
-                         int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
-                         int32_t* d_nmatched, hipStream_t s);
+// one launch of the row-band stereo search (device pointers; optional ones may be NULL)
+struct StereoLaunch {
+    const orbx_keypoint *d_kl, *d_kr;
+    const uint32_t *d_dl, *d_dr;
+    const int32_t *d_nl, *d_nr;
+    const uint8_t* d_active;
+    const float *d_min_d, *d_max_d;
+    int32_t* d_listed;
+    int32_t *d_best_idx, *d_best_dist;
+    float *d_u_right, *d_depth;
+    int32_t* d_nmatched;
+    int nbatch, stride, nrows, th_orb_dist, init_outputs, median_cut;
+    float mbf, mb, min_x;
+};
+void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s);
 
 void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
                            const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void k_match_bruteforce(const uint32_t* __rest
     const int b = blockIdx.z;
     const int qi = blockIdx.x * 256 + threadIdx.x;
     const int nQ = nq ? min(nq[b], q_stride) : Q;
-    const int nT = nt ? nt[b] : T;
+    const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
     const int chunk = (nT + tsplit - 1) / tsplit;
     const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
     if (qi >= nQ) return;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_match_bruteforce_mfma(
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
     const int nQ = nq ? min(nq[b], q_stride) : Q;
-    const int nT = nt ? nt[b] : T;
+    const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
     const int q0 = (blockIdx.x * kMfmaWaves + wave) * (32 * kMfmaQT);
     if (blockIdx.x * kMfmaWaves * (32 * kMfmaQT) >= nQ) return;         // whole workgroup past the queries
     const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
@@ -384,143 +384,172 @@ void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const i
 }
 
 // ---------------------------------------------------------------------------
-// Stereo: Frame::PrepareStereoCandidates (include/Frame.h:217-251) +
-// Frame::ComputeStereoMatches_Undistorted(false) (src/Frame.cc:1262-1422)
-// without map-point priors.  One workgroup per stereo pair.  A right keypoint
-// is a candidate of left keypoint iL iff int(vL) lies in its row band
-// [max(0,floor(y-r)), min(nRows-1, ceil(y+r))], r = 2*scaleFactor[octave];
-// candidates are visited in ascending iR, as the row table lists them.
+// Stereo: Frame::PrepareStereoCandidates (include/Frame.h:217-251) and the per-keypoint body of
+// Frame::ComputeStereoMatches_Undistorted (src/Frame.cc:1302-1395), which is also the body of
+// ComputeStereoMatch_OnePoint (:1189-1257) and the Hamming scan of ComputeStereoMatches (:1023-1068).
+// A right keypoint is a candidate of left keypoint iL iff int(vL) lies in its row band
+// [max(0, floor(y-r)), min(nRows-1, ceil(y+r))], r = 2*scaleFactor[octave]; the reference visits a
+// row's candidates in ascending iR and keeps the first minimum below TH_HIGH, i.e. the minimum of
+// (distance, iR), so no row table is materialised: one wavefront per left keypoint, its lanes
+// stride over the right keypoints, test band / octave / disparity window, and the wave minimum of
+// distance << 22 | iR is taken with DPP moves.  Work of a pair spreads over the whole device and
+// there is no limit on the number of keypoints.
 // ---------------------------------------------------------------------------
-constexpr int kStereoMaxRight = 4096;
-
-__global__ __launch_bounds__(256) void k_stereo_match(const orbx_keypoint* __restrict__ kl, const uint32_t* __restrict__ dl,
-                                                      const int32_t* __restrict__ nl_arr,
-                                                      const orbx_keypoint* __restrict__ kr, const uint32_t* __restrict__ dr,
-                                                      const int32_t* __restrict__ nr_arr, int stride, int nrows,
-                                                      ScaleTab sc, float mbf, float mb, float min_x,
-                                                      int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
-                                                      float* __restrict__ u_right, float* __restrict__ depth,
-                                                      int32_t* __restrict__ nmatched, int classic)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-    __shared__ short s_minr[kStereoMaxRight], s_maxr[kStereoMaxRight];
-    __shared__ float s_ur[kStereoMaxRight];
-    __shared__ signed char s_oct[kStereoMaxRight];
-    __shared__ int s_hist[128];
-    __shared__ int s_nv, s_nmatched, s_median;
+    // lanes without a source (and rows masked out) keep the identity
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x142, 0xa, 0xf, false));   // row_bcast15 into rows 1, 3
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x143, 0xc, 0xf, false));   // row_bcast31 into rows 2, 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+struct StereoArgs {
+    const orbx_keypoint *kl, *kr;
+    const uint32_t *dl, *dr;
+    const int32_t *nl, *nr;
+    const uint8_t* active;          // per left keypoint, or NULL = all
+    const float *min_d, *max_d;     // per left keypoint disparity window, or NULL = [0, mbf / mb)
+    int32_t* listed;                // mvDistIdx as an array: accepted distance per left keypoint, -1 = not listed
+    int32_t *best_idx, *best_dist;
+    float *u_right, *depth;
+    int32_t* nmatched;
+    int stride, nrows, th_orb_dist;
+    float mbf, mb, min_x;
+    int classic;                    // Frame::ComputeStereoMatches: row test of :1031-1033, no disparity here
+    int init_outputs;               // u_right = depth = listed = -1 for every left keypoint first
+    int median_cut;
+};
+
+__global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int iL = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int nl = min(a.nl[b], a.stride), nr = min(a.nr[b], a.stride);
+    if (iL >= nl) return;
+    const size_t o = (size_t)b * a.stride + iL;
+    if (a.init_outputs && lane == 0) {
+        a.u_right[o] = -1.0f;
+        a.depth[o] = -1.0f;
+        if (a.listed) a.listed[o] = -1;
+    }
+    if (a.active && !a.active[o]) return;
+    const orbx_keypoint k = a.kl[o];
+    const float minD = a.min_d ? a.min_d[o] : 0.0f;
+    const float maxD = a.max_d ? a.max_d[o] : __fdiv_rn(a.mbf, a.mb);
+    const float vL = k.y, uL = k.x;
+    const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
+    const int row = (int)vL;
+    const bool row_ok = a.classic ? (row >= 0 && row < a.nrows) : !(vL < 0 || vL > (float)(a.nrows - 1));
+    uint32_t key = 0xffffffffu;
+    bool any = false;
+    if (row_ok && !(maxU < a.min_x)) {
+        uint32_t qd[8];
+        const uint4* qp = reinterpret_cast<const uint4*>(a.dl + o * 8);
+        const uint4 q0 = qp[0], q1 = qp[1];
+        qd[0] = q0.x; qd[1] = q0.y; qd[2] = q0.z; qd[3] = q0.w;
+        qd[4] = q1.x; qd[5] = q1.y; qd[6] = q1.z; qd[7] = q1.w;
+        const orbx_keypoint* kr = a.kr + (size_t)b * a.stride;
+        const uint32_t* dr = a.dr + (size_t)b * a.stride * 8;
+        const float last_row = (float)(a.nrows - 1);
+        for (int iR = lane; iR < nr; iR += 64) {
+            const float yR = kr[iR].y, uR = kr[iR].x;
+            const int oR = kr[iR].octave;
+            const float r = __fmul_rn(2.0f, sc.v[min(max(oR, 0), kMaxLevels - 1)]);
+            const int hi = (int)fminf(last_row, ceilf(__fadd_rn(yR, r)));
+            const int lo = (int)fmaxf(0.0f, floorf(__fsub_rn(yR, r)));
+            if (row < lo || row > hi) continue;
+            any = true;
+            if (oR < k.octave - 1 || oR > k.octave + 1) continue;
+            if (uR >= minU && uR <= maxU) {
+                const uint4* tp = reinterpret_cast<const uint4*>(dr + (size_t)iR * 8);
+                const int d = hamming256(qd, tp[0], tp[1]);
+                key = min(key, ((uint32_t)d << 22) | (uint32_t)iR);
+            }
+        }
+    }
+    any = __ballot(any) != 0ull;
+    key = wave_min_u32(key);
+    if (lane != 0) return;
+    if (!any) {                                     // left before the scan: 'continue' / 'return false'
+        a.best_idx[o] = -1;
+        a.best_dist[o] = 100;
+        return;
+    }
+    const bool found = (key >> 22) < 100u;          // bestDist starts at TH_HIGH, strict '<'
+    const int bdist = found ? (int)(key >> 22) : 100;
+    const int bidx = found ? (int)(key & 0x3FFFFFu) : 0;
+    a.best_idx[o] = bidx;
+    a.best_dist[o] = bdist;
+    if (!a.classic && bdist < a.th_orb_dist) {
+        float bestuR = a.kr[(size_t)b * a.stride + bidx].x;
+        float disparity = __fsub_rn(uL, bestuR);
+        if (disparity >= minD && disparity < maxD) {
+            if (disparity <= 0) {
+                disparity = 0.01f;
+                bestuR = (float)((double)uL - 0.01);
+            }
+            a.depth[o] = __fdiv_rn(a.mbf, disparity);
+            a.u_right[o] = bestuR;
+            if (a.listed) a.listed[o] = bdist;
+        }
+    }
+}
+
+// nmatched of src/Frame.cc:1397 (keypoints of this call that reached the scan) and the cut at
+// 2.1 x the median of all listed distances (:1400-1419).  One workgroup per pair.
+__global__ __launch_bounds__(256) void k_stereo_finish(StereoArgs a)
+{
+    __shared__ int s_hist[257];
+    __shared__ int s_scanned, s_nv, s_removed, s_median;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int nl = min(nl_arr[b], stride), nr = min(min(nr_arr[b], stride), kStereoMaxRight);
-    kl += (size_t)b * stride; kr += (size_t)b * stride;
-    dl += (size_t)b * stride * 8; dr += (size_t)b * stride * 8;
-    best_idx += (size_t)b * stride; best_dist += (size_t)b * stride;
-    u_right += (size_t)b * stride; depth += (size_t)b * stride;
-
-    for (int i = tid; i < nr; i += 256) {
-        const orbx_keypoint k = kr[i];
-        const float r = __fmul_rn(2.0f, sc.v[min(max(k.octave, 0), kMaxLevels - 1)]);
-        const float hi = fminf((float)(nrows - 1), ceilf(__fadd_rn(k.y, r)));
-        const float lo = fmaxf(0.0f, floorf(__fsub_rn(k.y, r)));
-        s_maxr[i] = (short)(int)hi;
-        s_minr[i] = (short)(int)lo;
-        s_ur[i] = k.x;
-        s_oct[i] = (signed char)k.octave;
-    }
-    for (int i = tid; i < 128; i += 256) s_hist[i] = 0;
-    if (tid == 0) { s_nv = 0; s_nmatched = 0; }
+    const int nl = min(a.nl[b], a.stride);
+    const size_t base = (size_t)b * a.stride;
+    for (int i = tid; i < 257; i += 256) s_hist[i] = 0;
+    if (tid == 0) { s_scanned = 0; s_nv = 0; s_removed = 0; s_median = -1; }
     __syncthreads();
-
-    const float minD = 0.0f;
-    const float maxD = __fdiv_rn(mbf, mb);
-    const int thOrbDist = (100 + 50) / 2;   // (TH_HIGH + TH_LOW) / 2
-    int my_matched = 0, my_nv = 0;
-    uint32_t accepted = 0;   // bit k: left keypoint tid + 256*k got a disparity
-    for (int iL = tid, kk = 0; iL < nl; iL += 256, kk++) {
-        const orbx_keypoint k = kl[iL];
-        int bidx = -1, bdist = 100;
-        float ur = -1.0f, dp = -1.0f;
-        const float vL = k.y, uL = k.x;
-        const float minU = __fsub_rn(uL, maxD), maxU = __fsub_rn(uL, minD);
-        const int row = (int)vL;
-        const bool row_ok = classic ? (row >= 0 && row < nrows) : !(vL < 0 || vL > (float)(nrows - 1));
-        if (row_ok && !(maxU < min_x)) {
-            uint32_t qd[8];
-            const uint4* qp = reinterpret_cast<const uint4*>(dl + (size_t)iL * 8);
-            uint4 a = qp[0], c = qp[1];
-            qd[0] = a.x; qd[1] = a.y; qd[2] = a.z; qd[3] = a.w;
-            qd[4] = c.x; qd[5] = c.y; qd[6] = c.z; qd[7] = c.w;
-            bool any = false;
-            int bestIdxR = 0;
-            for (int iR = 0; iR < nr; iR++) {
-                if (row < s_minr[iR] || row > s_maxr[iR]) continue;
-                any = true;
-                const int o = s_oct[iR];
-                if (o < k.octave - 1 || o > k.octave + 1) continue;
-                const float uR = s_ur[iR];
-                if (uR >= minU && uR <= maxU) {
-                    const uint4* tp = reinterpret_cast<const uint4*>(dr + (size_t)iR * 8);
-                    const int d = hamming256(qd, tp[0], tp[1]);
-                    if (d < bdist) { bdist = d; bestIdxR = iR; }
-                }
-            }
-            if (any) {
-                bidx = bestIdxR;
-                my_matched++;
-                if (!classic && bdist < thOrbDist) {
-                    float bestuR = s_ur[bestIdxR];
-                    float disparity = __fsub_rn(uL, bestuR);
-                    if (disparity >= minD && disparity < maxD) {
-                        if (disparity <= 0) {
-                            disparity = 0.01f;
-                            bestuR = (float)((double)uL - 0.01);
-                        }
-                        dp = __fdiv_rn(mbf, disparity);
-                        ur = bestuR;
-                        atomicAdd(&s_hist[bdist], 1);
-                        my_nv++;
-                        accepted |= 1u << kk;
-                    }
-                }
-            } else {
-                bdist = 100;
-            }
+    int scanned = 0, nv = 0;
+    for (int iL = tid; iL < nl; iL += 256) {
+        const bool act = !a.active || a.active[base + iL];
+        if (act && a.best_idx[base + iL] >= 0) scanned++;
+        if (a.median_cut && a.listed) {
+            const int d = a.listed[base + iL];
+            if (d >= 0) { atomicAdd(&s_hist[min(d, 256)], 1); nv++; }
         }
-        best_idx[iL] = bidx;
-        best_dist[iL] = bdist;
-        u_right[iL] = ur;
-        depth[iL] = dp;
     }
-    if (my_matched) atomicAdd(&s_nmatched, my_matched);
-    if (my_nv) atomicAdd(&s_nv, my_nv);
+    if (scanned) atomicAdd(&s_scanned, scanned);
+    if (nv) atomicAdd(&s_nv, nv);
     __syncthreads();
-    // median of the accepted distances (element nv/2 of the sorted list), src/Frame.cc:1402-1404
-    if (tid == 0) {
-        int med = -1;
-        if (s_nv > 0) {
-            int target = s_nv / 2, cum = 0;
-            for (int d = 0; d < 128; d++) {
-                cum += s_hist[d];
-                if (cum > target) { med = d; break; }
-            }
+    if (tid == 0 && s_nv > 0) {          // element nv/2 of the sorted distances
+        const int target = s_nv / 2;
+        int cum = 0;
+        for (int d = 0; d < 257; d++) {
+            cum += s_hist[d];
+            if (cum > target) { s_median = d; break; }
         }
-        s_median = med;
     }
     __syncthreads();
-    int removed = 0;
     if (s_median >= 0) {
         const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
-        for (int iL = tid, kk = 0; iL < nl; iL += 256, kk++) {
-            if ((accepted >> kk) & 1) {
-                if (!((float)best_dist[iL] < thDist)) {
-                    u_right[iL] = -1.0f;
-                    depth[iL] = -1.0f;
-                    removed++;
-                }
+        int removed = 0;
+        for (int iL = tid; iL < nl; iL += 256) {
+            const int d = a.listed[base + iL];
+            if (d >= 0 && !((float)d < thDist)) {
+                a.u_right[base + iL] = -1.0f;
+                a.depth[base + iL] = -1.0f;
+                removed++;
             }
         }
+        if (removed) atomicAdd(&s_removed, removed);
     }
-    if (removed) atomicSub(&s_nmatched, removed);
     __syncthreads();
-    if (tid == 0 && !classic) nmatched[b] = s_nmatched;
+    if (tid == 0) a.nmatched[b] = s_scanned - s_removed;
 }
+
+constexpr int kStereoMaxRight = 4096;    // keypoints per image of the SAD refinement and of the frame grid (LDS lists)
 
 // ---------------------------------------------------------------------------
 // Classic stereo refinement, Frame::ComputeStereoMatches src/Frame.cc:1070-1172:
@@ -654,16 +683,20 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
     if (tid == 0) nmatched[b] = s_nacc;
 }
 
-void launch_stereo_match(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
-                         const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
-                         int nbatch, int stride, int nrows, const float* scale8, float mbf, float mb, float min_x,
-                         int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
-                         int32_t* d_nmatched, hipStream_t s)
+void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s)
 {
     ScaleTab sc;
     for (int i = 0; i < kMaxLevels; i++) sc.v[i] = scale8[i];
-    hipLaunchKernelGGL(k_stereo_match, dim3(nbatch), dim3(256), 0, s, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, stride,
-                       nrows, sc, mbf, mb, min_x, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, 0);
+    StereoArgs a;
+    a.kl = L.d_kl; a.kr = L.d_kr; a.dl = L.d_dl; a.dr = L.d_dr; a.nl = L.d_nl; a.nr = L.d_nr;
+    a.active = L.d_active; a.min_d = L.d_min_d; a.max_d = L.d_max_d; a.listed = L.d_listed;
+    a.best_idx = L.d_best_idx; a.best_dist = L.d_best_dist; a.u_right = L.d_u_right; a.depth = L.d_depth;
+    a.nmatched = L.d_nmatched;
+    a.stride = L.stride; a.nrows = L.nrows; a.th_orb_dist = L.th_orb_dist;
+    a.mbf = L.mbf; a.mb = L.mb; a.min_x = L.min_x;
+    a.classic = 0; a.init_outputs = L.init_outputs; a.median_cut = L.median_cut;
+    hipLaunchKernelGGL(k_stereo_scan, dim3((L.stride + 3) / 4, L.nbatch), dim3(256), 0, s, a, sc);
+    hipLaunchKernelGGL(k_stereo_finish, dim3(L.nbatch), dim3(256), 0, s, a);
 }
 
 void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
@@ -676,8 +709,15 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
     ScaleTab sc, isc;
     for (int i = 0; i < kMaxLevels; i++) { sc.v[i] = scale8[i]; isc.v[i] = inv_scale8[i]; }
     const int nrows = g.lv[0].h;
-    hipLaunchKernelGGL(k_stereo_match, dim3(nbatch), dim3(256), 0, s, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, stride,
-                       nrows, sc, mbf, mb, 0.0f, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched, 1);
+    StereoArgs a;
+    a.kl = d_kl; a.kr = d_kr; a.dl = d_dl; a.dr = d_dr; a.nl = d_nl; a.nr = d_nr;
+    a.active = nullptr; a.min_d = nullptr; a.max_d = nullptr; a.listed = nullptr;
+    a.best_idx = d_best_idx; a.best_dist = d_best_dist; a.u_right = d_u_right; a.depth = d_depth;
+    a.nmatched = d_nmatched;
+    a.stride = stride; a.nrows = nrows; a.th_orb_dist = 75;
+    a.mbf = mbf; a.mb = mb; a.min_x = 0.0f;
+    a.classic = 1; a.init_outputs = 1; a.median_cut = 0;
+    hipLaunchKernelGGL(k_stereo_scan, dim3((stride + 3) / 4, nbatch), dim3(256), 0, s, a, sc);
     hipLaunchKernelGGL(k_stereo_sad, dim3(nbatch), dim3(256), 0, s, d_kl, d_nl, d_kr, stride, pyrL, pyrR, g, sc, isc,
                        mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
 }

@@ -94,6 +94,37 @@ class ORBmatcher:
             self._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr), nbatch, stride, nrows,
             mbf, mb, min_x, ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))
 
+    def stereo_match_ex(self, kl, dl, kr, dr, nrows, mbf, mb, min_x, active, min_d, max_d, th_orb_dist, median_cut,
+                        listed_dist, best_idx, best_dist, u_right, depth):
+        """orbx_stereo_match_ex: one call of the delayed stereo matching on a Frame's state arrays
+        (updated in place); returns nmatched"""
+        kl = np.ascontiguousarray(kl, KP_DTYPE)
+        kr = np.ascontiguousarray(kr, KP_DTYPE)
+        dl, dr = _desc(dl), _desc(dr)
+        nl, nr = len(kl), len(kr)
+        for a, t in ((listed_dist, np.int32), (best_idx, np.int32), (best_dist, np.int32),
+                     (u_right, np.float32), (depth, np.float32)):
+            if a.dtype != t or not a.flags.c_contiguous or len(a) < nl:
+                raise ValueError("state arrays must be contiguous %s arrays of nl entries" % t)
+        act = None if active is None else np.ascontiguousarray(active, np.uint8)
+        mn = None if min_d is None else np.ascontiguousarray(min_d, np.float32)
+        mx = None if max_d is None else np.ascontiguousarray(max_d, np.float32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match_ex(
+            self._ctx, kl.ctypes.data, dl.ctypes.data, nl, kr.ctypes.data if nr else None,
+            dr.ctypes.data if nr else None, nr, nrows, mbf, mb, min_x, ptr(act), ptr(mn), ptr(mx),
+            int(th_orb_dist), int(bool(median_cut)), listed_dist.ctypes.data, best_idx.ctypes.data,
+            best_dist.ctypes.data, u_right.ctypes.data, depth.ctypes.data, C.byref(nm)))
+        return nm.value
+
+    def stereo_match_ex_device(self, d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, nrows, mbf, mb, min_x,
+                               d_active, d_min_d, d_max_d, th_orb_dist, median_cut, d_listed,
+                               d_bi, d_bd, d_ur, d_dp, d_nm):
+        check(self._lib, self._ctx, self._lib.orbx_stereo_match_ex_device(
+            self._ctx, ptr(d_kl), ptr(d_dl), ptr(d_nl), ptr(d_kr), ptr(d_dr), ptr(d_nr), nbatch, stride, nrows,
+            mbf, mb, min_x, ptr(d_active), ptr(d_min_d), ptr(d_max_d), int(th_orb_dist), int(bool(median_cut)),
+            ptr(d_listed), ptr(d_bi), ptr(d_bd), ptr(d_ur), ptr(d_dp), ptr(d_nm)))
+
     def stereo_match_sad(self, right_extractor, kl, dl, kr, dr, mbf, mb):
         """Frame::ComputeStereoMatches (src/Frame.cc:984-1173): Hamming row-band search + SAD
         sub-pixel refinement on the pyramids of this matcher's extractor (left) and

@@ -36,8 +36,22 @@ def _ptr(a, t):
     return a.ctypes.data_as(t)
 
 
+class StereoState(C.Structure):
+    """oo_stereo_state: mvuRight, mvDepth, mvStereoMatched, mvDistIdx of a Frame"""
+    _fields_ = [("u_right", _f32p), ("depth", _f32p), ("stereo_matched", _u8p),
+                ("dist_idx_dist", _i32p), ("dist_idx_il", _i32p), ("n_dist_idx", C.c_int32)]
+
+
+TRIG_LIBM, TRIG_ROUNDED = 0, 1
+
+
 class Oracle:
-    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, native=False):
+    """trig: how computeOrbDescriptor's cos / sin are taken.  "rounded" (default here) = correctly
+    rounded, the formulation the GPU kernel evaluates, so that descriptor comparisons are exact;
+    "libm" = this host's cosf / sinf as the reference calls them (differs in the last bit for
+    about 0.1 % of all angles; see oracle/orb_oracle.h)."""
+
+    def __init__(self, nfeatures=1000, scale=1.2, nlevels=8, ini_th=20, min_th=7, native=False, trig="rounded"):
         self.lib = lib = C.CDLL(build(native))
         lib.oo_create.restype = C.c_void_p
         lib.oo_create.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int]
@@ -75,10 +89,22 @@ class Oracle:
                                             _f32p, _f32p, _f32p, _i32p, _i32p, C.c_int, _i32p, _i32p, C.c_int]
         lib.oo_undistort_points.argtypes = [_f32p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                             C.c_int, C.c_int, _f32p]
+        lib.oo_set_trig_mode.argtypes = [C.c_void_p, C.c_int]
+        lib.oo_orb_descriptor_mode.argtypes = [C.c_void_p, C.c_int, C.c_float, _u8p, C.c_int]
+        lib.oo_count_trig_differences.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.oo_stereo_prepare.argtypes = [C.POINTER(StereoState), C.c_int]
+        lib.oo_stereo_undistorted.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int, _f32p, C.c_int,
+                                              C.c_float, C.c_float, C.c_float, C.c_float, _u8p, _f32p, C.c_int,
+                                              C.POINTER(StereoState), _i32p, _i32p]
+        lib.oo_stereo_one_point.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int, _f32p, C.c_int,
+                                            C.c_float, _u8p, C.c_int, C.c_int, C.c_float, C.c_float,
+                                            C.POINTER(StereoState), _i32p, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
             raise ValueError("oo_create failed")
+        self.trig = {"rounded": TRIG_ROUNDED, "libm": TRIG_LIBM}[trig]
+        lib.oo_set_trig_mode(self.h, self.trig)
         self._img_shape = None
 
     def __del__(self):
@@ -185,8 +211,17 @@ class Oracle:
     def descriptor(self, img, x, y, angle_deg):
         img = np.ascontiguousarray(img, np.uint8)
         d = np.zeros(32, np.uint8)
-        self.lib.oo_orb_descriptor(img.ctypes.data + y * img.shape[1] + x, img.shape[1], angle_deg, _ptr(d, _u8p))
+        self.lib.oo_orb_descriptor_mode(img.ctypes.data + y * img.shape[1] + x, img.shape[1], angle_deg, _ptr(d, _u8p),
+                                        self.trig)
         return d
+
+    def count_trig_differences(self, first=0, step=1):
+        """(cos differences, sin differences, angles tested) between libm cosf / sinf and the correctly
+        rounded values over the float angles first, first + step, ... in [0, 360) degrees"""
+        counts = (C.c_uint64 * 2)()
+        tested = C.c_uint64()
+        self.lib.oo_count_trig_differences(first, step, counts, C.byref(tested))
+        return int(counts[0]), int(counts[1]), int(tested.value)
 
     # ---- full extraction ------------------------------------------------------
     def extract(self, img, literal=False, cap=None):
@@ -270,6 +305,9 @@ class Oracle:
                                       mbf, minD, maxD, _ptr(ur, _f32p), _ptr(dp, _f32p))
         return n, ur[:len(kl)], dp[:len(kl)]
 
+    def stereo_frame(self, kl, dl, kr, dr, scale_factors, nrows, mbf, mb, min_x=0.0):
+        return OracleStereoFrame(self, kl, dl, kr, dr, scale_factors, nrows, mbf, mb, min_x)
+
     def stereo_classic(self, right_oracle, kl, dl, kr, dr, mbf, mb):
         """self / right_oracle hold the pyramids of the left / right frame"""
         kl = np.ascontiguousarray(kl, KP_DTYPE)
@@ -308,3 +346,56 @@ class Oracle:
                                      None if R is None else R.ctypes.data, None if P is None else P.ctypes.data,
                                      0 if P is None else P.shape[1], 1 if fisheye else 0, _ptr(out, _f32p))
         return out
+
+
+class OracleStereoFrame:
+    """State + calls of the reference's delayed stereo matching (include/Frame.h:217-255) on the oracle"""
+
+    def __init__(self, oracle, kl, dl, kr, dr, scale_factors, nrows, mbf, mb, min_x):
+        self.o = oracle
+        self.kl = np.ascontiguousarray(kl, KP_DTYPE)
+        self.kr = np.ascontiguousarray(kr, KP_DTYPE)
+        self.dl = np.ascontiguousarray(dl, np.uint8).reshape(-1, 32)
+        self.dr = np.ascontiguousarray(dr, np.uint8).reshape(-1, 32)
+        self.sf = np.ascontiguousarray(scale_factors, np.float32)
+        self.nrows, self.mbf, self.mb, self.min_x = nrows, mbf, mb, min_x
+        n = max(len(self.kl), 1)
+        self.N = len(self.kl)
+        self.mvuRight = np.zeros(n, np.float32)
+        self.mvDepth = np.zeros(n, np.float32)
+        self.mvStereoMatched = np.zeros(n, np.uint8)
+        self.di_dist = np.zeros(n, np.int32)
+        self.di_il = np.zeros(n, np.int32)
+        self.has_mappoint = np.zeros(n, np.uint8)
+        self.prior_disp = np.zeros(n, np.float32)
+        self.best_idx = np.full(n, -1, np.int32)
+        self.best_dist = np.full(n, 100, np.int32)
+        self.st = StereoState(_ptr(self.mvuRight, _f32p), _ptr(self.mvDepth, _f32p), _ptr(self.mvStereoMatched, _u8p),
+                              _ptr(self.di_dist, _i32p), _ptr(self.di_il, _i32p), 0)
+        self.PrepareStereoCandidates()
+
+    def PrepareStereoCandidates(self):
+        self.o.lib.oo_stereo_prepare(C.byref(self.st), self.N)
+
+    def listed_dist(self):
+        """mvDistIdx as an array over left keypoints (-1 = not listed)"""
+        out = np.full(max(self.N, 1), -1, np.int32)
+        n = self.st.n_dist_idx
+        out[self.di_il[:n]] = self.di_dist[:n]
+        return out
+
+    def _common(self):
+        return (self.kl.ctypes.data, _ptr(self.dl.view(np.uint32), _u32p), self.N,
+                self.kr.ctypes.data, _ptr(self.dr.view(np.uint32), _u32p), len(self.kr),
+                _ptr(self.sf, _f32p), self.nrows)
+
+    def ComputeStereoMatches_Undistorted(self, isOnline=False, disparity_thres=50.0):
+        return self.o.lib.oo_stereo_undistorted(*self._common(), self.mbf, self.mb, self.min_x, disparity_thres,
+                                                _ptr(self.has_mappoint, _u8p), _ptr(self.prior_disp, _f32p),
+                                                int(isOnline), C.byref(self.st), _ptr(self.best_idx, _i32p),
+                                                _ptr(self.best_dist, _i32p))
+
+    def ComputeStereoMatch_OnePoint(self, iL, thOrbDist, minD, maxD):
+        return bool(self.o.lib.oo_stereo_one_point(*self._common(), self.mbf, _ptr(self.has_mappoint, _u8p), iL,
+                                                   thOrbDist, minD, maxD, C.byref(self.st), _ptr(self.best_idx, _i32p),
+                                                   _ptr(self.best_dist, _i32p)))

@@ -1,0 +1,171 @@
+"""The shapes bench.py times, compared with the CPU oracle: the resident 256-frame batch on a
+caller's stream (frame-per-XCD mapping, 256-thread quadtree shape), the KITTI-size and 4K batches,
+and the brute-force Hamming legs at their full sizes (split train set + merge)."""
+import concurrent.futures as cf
+
+import numpy as np
+import pytest
+
+from oracle_lib import Oracle
+from orb_slam_amd.synth import synthetic_frame, random_descriptors, map_descriptors
+
+pytestmark = pytest.mark.gpu
+NTHREADS = 8
+
+
+def _oracle_frames(params, frames):
+    """oracle keypoints / descriptors of many frames, one oracle per worker thread (ctypes drops the GIL)"""
+    def work(chunk):
+        o = Oracle(*params)
+        return [o.extract(f, literal=True) for f in chunk]
+    chunks = [frames[i::NTHREADS] for i in range(NTHREADS)]
+    with cf.ThreadPoolExecutor(NTHREADS) as pool:
+        parts = list(pool.map(work, chunks))
+    out = [None] * len(frames)
+    for k, part in enumerate(parts):
+        for j, r in enumerate(part):
+            out[k + j * NTHREADS] = r
+    return out
+
+
+def _run_resident(params, host, check_idx):
+    """extract_batch_device exactly as bench.py calls it; returns per-frame (keypoints, descriptors)"""
+    import torch
+    from orb_slam_amd import ORBextractor, KP_DTYPE
+    B, H, W = host.shape
+    dev = torch.device("cuda", 0)
+    ex = ORBextractor(*params, device=0)
+    cap = ex.max_keypoints(W, H)
+    d_imgs = torch.from_numpy(host).to(dev)
+    d_kps = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+    d_desc = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+    d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ex.set_stream(stream.cuda_stream)
+        for _ in range(2):       # the second pass runs on warmed-up buffers, as the timed steps do
+            ex.extract_batch_device(d_imgs, B, W, H, W, W * H, d_kps, d_desc, cap, d_n)
+        stream.synchronize()
+        ex.set_stream(None)
+    n = d_n.cpu().numpy()
+    assert (n <= cap).all()
+    out = {}
+    for i in check_idx:
+        k = d_kps[i, :n[i]].cpu().numpy().copy().view(KP_DTYPE).reshape(-1)
+        out[i] = (k, d_desc[i, :n[i]].cpu().numpy())
+    ex.close()
+    return out, n
+
+
+def _assert_same(got, ref, what):
+    (kg, dg), (ko, do) = got, ref
+    assert len(kg) == len(ko), what
+    assert np.array_equal(kg, ko), what           # all seven fields, angle included, bit for bit
+    assert np.array_equal(dg, do), what
+
+
+def test_bench_batch_256_frames_every_frame():
+    """BASELINE config 2 as benchmarked: frames synthetic_frame(752, 480, 1234 + i), resident, own stream"""
+    params = (1000, 1.2, 8, 20, 7)
+    host = np.stack([synthetic_frame(752, 480, 1234 + i) for i in range(256)])
+    got, n = _run_resident(params, host, range(256))
+    ref = _oracle_frames(params, list(host))
+    for i in range(256):
+        _assert_same(got[i], ref[i], "frame %d" % i)
+    assert n.mean() > 900
+
+
+def test_bench_batch_kitti_2000():
+    """BASELINE config 4 shape: 256 frames 1241x376, 2000 features (every 8th frame checked)"""
+    params = (2000, 1.2, 8, 20, 7)
+    host = np.stack([synthetic_frame(1241, 376, 777 + i) for i in range(256)])
+    idx = list(range(0, 256, 8)) + [255]
+    got, n = _run_resident(params, host, idx)
+    ref = _oracle_frames(params, [host[i] for i in idx])
+    for j, i in enumerate(idx):
+        _assert_same(got[i], ref[j], "frame %d" % i)
+    assert n.mean() > 1800
+
+
+def test_bench_batch_4k_8000():
+    """BASELINE config 5 shape: 8 frames 3840x2160, 8000 features"""
+    params = (8000, 1.2, 8, 20, 7)
+    host = np.stack([synthetic_frame(3840, 2160, 99 + i, nrect=1500) for i in range(8)])
+    got, n = _run_resident(params, host, range(8))
+    ref = _oracle_frames(params, list(host))
+    for i in range(8):
+        _assert_same(got[i], ref[i], "frame %d" % i)
+    assert n.mean() > 7000
+
+
+def _oracle_bruteforce_mt(q, t):
+    def work(part):
+        return Oracle().match_bruteforce(part, t)
+    parts = np.array_split(q, NTHREADS)
+    with cf.ThreadPoolExecutor(NTHREADS) as pool:
+        res = list(pool.map(work, parts))
+    return tuple(np.concatenate([r[k] for r in res]) for k in range(3))
+
+
+def test_bench_match_8000_x_100000():
+    """config 5: 8000 frame descriptors against a 100 000-point map with planted near-duplicates
+    and exact duplicates; the train set is split over workgroups and merged"""
+    import torch
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    Q, T = 8000, 100000
+    q = random_descriptors(Q, 5)
+    t = map_descriptors(T, q, seed=99, planted=0.10)
+    t[70000] = t[123]            # exact duplicates far apart: the lower index must win across the split
+    q[17] = t[123]
+    t[99999] = q[18]             # best match in the very last train row
+    t[0] = q[19]
+    dev = torch.device("cuda", 0)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex)
+    dq, dt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    outs = [torch.full((Q,), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        ex.set_stream(stream.cuda_stream)
+        m.match_bruteforce_device(dq, Q, Q, None, dt, T, T, None, 1, *outs)
+        stream.synchronize()
+        ex.set_stream(None)
+    oi, od, os_ = _oracle_bruteforce_mt(q, t)
+    assert np.array_equal(outs[0].cpu().numpy(), oi)
+    assert np.array_equal(outs[1].cpu().numpy(), od)
+    assert np.array_equal(outs[2].cpu().numpy(), os_)
+    assert oi[17] == 123 and od[17] == 0 and os_[17] == 0 and oi[18] == 99999 and oi[19] == 0
+    ex.close()
+
+
+def test_bench_match_128_x_1000_x_1000():
+    """config 3: 128 independent 1000 x 1000 searches in one launch"""
+    import torch
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    nb, Q = 128, 1000
+    rng = np.random.default_rng(99)
+    q = rng.integers(0, 256, (nb, Q, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nb, Q, 32), dtype=np.uint8)
+    t[:, 500] = q[:, 3]
+    t[:, 900] = q[:, 3]
+    dev = torch.device("cuda", 0)
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex)
+    dq, dt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    outs = [torch.full((nb, Q), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.match_bruteforce_device(dq, Q, Q, None, dt, Q, Q, None, nb, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    got = [o.cpu().numpy() for o in outs]
+
+    def work(bs):
+        o = Oracle()
+        return [o.match_bruteforce(q[b], t[b]) for b in bs]
+    with cf.ThreadPoolExecutor(NTHREADS) as pool:
+        parts = list(pool.map(work, [range(k, nb, NTHREADS) for k in range(NTHREADS)]))
+    for k, part in enumerate(parts):
+        for j, (oi, od, os_) in enumerate(part):
+            b = k + j * NTHREADS
+            assert np.array_equal(got[0][b], oi) and np.array_equal(got[1][b], od) and np.array_equal(got[2][b], os_), b
+    ex.close()

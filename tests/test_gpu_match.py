@@ -249,3 +249,147 @@ def test_grid_candidates_and_fused_search(ex, matcher, oracle, euroc_left):
     off_o, idx_o = oracle.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
     off_g, idx_g = matcher.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
     assert np.array_equal(off_g, off_o) and np.array_equal(idx_g, idx_o)
+
+
+def _random_stereo_sets(rng, n, w=752, h=480, planted=None):
+    """left / right keypoints with descriptors; `planted` right keypoints are true matches"""
+    planted = n // 2 if planted is None else planted
+    kl = np.zeros(n, KP_DTYPE)
+    kr = np.zeros(n, KP_DTYPE)
+    for k in (kl, kr):
+        k["x"] = rng.uniform(0, w, n).astype(np.float32)
+        k["y"] = rng.uniform(-3, h + 3, n).astype(np.float32)
+        k["octave"] = rng.integers(0, 8, n)
+    dl = random_descriptors(n, int(rng.integers(1 << 30)))
+    dr = random_descriptors(n, int(rng.integers(1 << 30)))
+    p = planted
+    kr["y"][:p] = kl["y"][:p] + rng.uniform(-1, 1, p).astype(np.float32)
+    kr["x"][:p] = kl["x"][:p] - rng.uniform(-2, 90, p).astype(np.float32)      # a few negative disparities
+    kr["octave"][:p] = np.clip(kl["octave"][:p] + rng.integers(-1, 2, p), 0, 7)
+    dr[:p] = dl[:p]
+    flips = rng.integers(0, 60, p)                                            # distances 0 .. 59 around thOrbDist / 2
+    for i in range(p):
+        bits = rng.choice(256, flips[i], replace=False)
+        np.bitwise_xor.at(dr[i], bits // 8, (1 << (bits % 8)).astype(np.uint8))
+    perm = rng.permutation(n)
+    return kl, dl, kr[perm], dr[perm]
+
+
+def _assert_stereo_state(sf_gpu, sf_orc, step):
+    n = sf_gpu.N
+    assert np.array_equal(sf_gpu.mvStereoMatched[:n], sf_orc.mvStereoMatched[:n] != 0), step
+    assert np.array_equal(sf_gpu.listed_dist[:n], sf_orc.listed_dist()[:n]), step
+    assert np.array_equal(sf_gpu.mvuRight[:n], sf_orc.mvuRight[:n]), step
+    assert np.array_equal(sf_gpu.mvDepth[:n], sf_orc.mvDepth[:n]), step
+    scanned = sf_orc.best_idx[:n] >= 0
+    assert np.array_equal(sf_gpu.best_idx[:n] >= 0, scanned), step
+    assert np.array_equal(sf_gpu.best_idx[:n][scanned], sf_orc.best_idx[:n][scanned]), step
+    assert np.array_equal(sf_gpu.best_dist[:n][scanned], sf_orc.best_dist[:n][scanned]), step
+
+
+@pytest.mark.parametrize("n,seed", [(1000, 1), (5000, 2), (37, 3)])
+def test_stereo_delayed_matching(ex, matcher, oracle, n, seed):
+    """The default build's stereo flow (DELAYED_STEREO_MATCHING): PrepareStereoCandidates, an online
+    call restricted to keypoints with map points and narrowed disparity windows, single-point calls,
+    then the offline call with the median cut over everything listed so far.  5000 keypoints per
+    image is beyond what the first stereo kernel accepted."""
+    from orb_slam_amd import StereoFrame
+    rng = np.random.default_rng(seed)
+    kl, dl, kr, dr = _random_stereo_sets(rng, n)
+    sf = ex.GetScaleFactors()
+    mbf, mb, min_x = 47.9, 0.11, 3.5
+    g = StereoFrame(matcher, kl, dl, kr, dr, 480, mbf, mb, min_x)
+    o = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, mbf, mb, min_x)
+    _assert_stereo_state(g, o, "prepare")
+    # tracker state: 40 % of the left keypoints have a map point; 3/4 of those project with a usable prior
+    has_mp = (rng.random(n) < 0.4).astype(np.uint8)
+    prior = np.where(rng.random(n) < 0.75, rng.uniform(0.5, 120, n), -1.0).astype(np.float32)
+    true_disp = np.float32(47.9) / np.float32(0.11)
+    prior[::7] = true_disp          # prior at the upper end: maxD clamps to mbf / mb
+    for f in (g, o):
+        f.has_mappoint[:n] = has_mp
+        f.prior_disp[:n] = prior
+    nm_g = g.ComputeStereoMatches_Undistorted(True)
+    nm_o = o.ComputeStereoMatches_Undistorted(True)
+    assert nm_g == nm_o
+    _assert_stereo_state(g, o, "online")
+    # new map-point associations, matched one at a time (Observability / SearchByProjection_OnePoint)
+    fresh = np.flatnonzero(has_mp == 0)[:12]
+    for f in (g, o):
+        f.has_mappoint[fresh] = 1
+    for j, iL in enumerate(list(fresh) + [int(np.flatnonzero(has_mp)[0]), -1, n]):
+        th = (75, 60, 100)[j % 3]
+        mn, mx = float(rng.uniform(0, 20)), float(rng.uniform(30, 400))
+        rg = g.ComputeStereoMatch_OnePoint(int(iL), th, mn, mx)
+        ro = o.ComputeStereoMatch_OnePoint(int(iL), th, mn, mx)
+        assert rg == ro, iL
+    _assert_stereo_state(g, o, "one point")
+    nm_g = g.ComputeStereoMatches_Undistorted(False)
+    nm_o = o.ComputeStereoMatches_Undistorted(False)
+    assert nm_g == nm_o
+    _assert_stereo_state(g, o, "offline")
+    if n >= 1000:
+        assert (g.mvuRight[:n] >= 0).sum() > n // 10
+        assert ((g.listed_dist[:n] >= 0) & (g.mvuRight[:n] < 0)).sum() > 0      # the median cut removed something
+    # a second offline call finds nothing left to do
+    assert g.ComputeStereoMatches_Undistorted(False) == o.ComputeStereoMatches_Undistorted(False)
+    _assert_stereo_state(g, o, "offline again")
+
+
+def test_stereo_ex_device_batched(ex, matcher, oracle):
+    """orbx_stereo_match_ex_device over several pairs with ragged counts, masks and windows"""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(9)
+    nb, stride = 4, 1200
+    sf = ex.GetScaleFactors()
+    mbf, mb, min_x = 47.9, 0.11, 0.0
+    kl = np.zeros((nb, stride), KP_DTYPE); kr = np.zeros((nb, stride), KP_DTYPE)
+    dl = np.zeros((nb, stride, 32), np.uint8); dr = np.zeros((nb, stride, 32), np.uint8)
+    nl = np.array([1200, 700, 1, 0], np.int32); nr = np.array([900, 1200, 5, 30], np.int32)
+    act = (rng.random((nb, stride)) < 0.6).astype(np.uint8)
+    prior = np.where(rng.random((nb, stride)) < 0.7, rng.uniform(0.5, 120, (nb, stride)), -1.0).astype(np.float32)
+    frames = []
+    for b in range(nb):
+        m = max(int(nl[b]), int(nr[b]), 1)
+        a, da, c, dc = _random_stereo_sets(rng, m)
+        kl[b, :m], dl[b, :m], kr[b, :m], dr[b, :m] = a, da, c, dc
+        o = oracle.stereo_frame(kl[b, :nl[b]], dl[b, :nl[b]], kr[b, :nr[b]], dr[b, :nr[b]], sf, 480, mbf, mb, min_x)
+        o.has_mappoint[:nl[b]] = act[b, :nl[b]]
+        o.prior_disp[:nl[b]] = prior[b, :nl[b]]
+        frames.append(o)
+    full = np.float32(mbf) / np.float32(mb)
+    use = (act != 0) & (prior > 0)
+    min_d = np.where(use, np.maximum(prior - np.float32(50), np.float32(0)), np.float32(0)).astype(np.float32)
+    max_d = np.where(use, np.minimum(prior + np.float32(50), full), full).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8) if a.dtype == KP_DTYPE else a).to(dev)
+    d_kl, d_kr, d_dl, d_dr = t(kl), t(kr), t(dl), t(dr)
+    d_nl, d_nr, d_act, d_min, d_max = t(nl), t(nr), t(act), t(min_d), t(max_d)
+    d_listed = torch.full((nb, stride), -1, dtype=torch.int32, device=dev)
+    d_bi = torch.full((nb, stride), -9, dtype=torch.int32, device=dev)
+    d_bd = torch.full((nb, stride), -9, dtype=torch.int32, device=dev)
+    d_ur = torch.full((nb, stride), -1.0, dtype=torch.float32, device=dev)
+    d_dp = torch.full((nb, stride), -1.0, dtype=torch.float32, device=dev)
+    d_nm = torch.zeros(nb, dtype=torch.int32, device=dev)
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    # online (masked, windows), then offline on the rest with the cut
+    matcher.stereo_match_ex_device(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nb, stride, 480, mbf, mb, min_x,
+                                   d_act, d_min, d_max, 75, False, d_listed, d_bi, d_bd, d_ur, d_dp, d_nm)
+    torch.cuda.synchronize()
+    nm1 = d_nm.cpu().numpy().copy()
+    d_rest = (1 - d_act).contiguous()
+    full_min = torch.zeros((nb, stride), dtype=torch.float32, device=dev)
+    full_max = torch.full((nb, stride), float(full), dtype=torch.float32, device=dev)
+    matcher.stereo_match_ex_device(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nb, stride, 480, mbf, mb, min_x,
+                                   d_rest, full_min, full_max, 75, True, d_listed, d_bi, d_bd, d_ur, d_dp, d_nm)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    nm2 = d_nm.cpu().numpy()
+    listed, ur, dp = d_listed.cpu().numpy(), d_ur.cpu().numpy(), d_dp.cpu().numpy()
+    for b in range(nb):
+        o, n = frames[b], int(nl[b])
+        assert o.ComputeStereoMatches_Undistorted(True) == nm1[b], b
+        assert o.ComputeStereoMatches_Undistorted(False) == nm2[b], b
+        assert np.array_equal(listed[b, :n], o.listed_dist()[:n]), b
+        assert np.array_equal(ur[b, :n], o.mvuRight[:n]) and np.array_equal(dp[b, :n], o.mvDepth[:n]), b
+        assert (listed[b, n:] == -1).all() and (ur[b, n:] == -1).all()

@@ -499,3 +499,110 @@ def test_undistort_fisheye_inverts_forward_model(oracle):
     # the centre maps to the origin exactly (theta_d <= 1e-8 keeps scale 1)
     c = oracle.undistort_points(np.array([[376.0, 240.0]], np.float32), K, k, fisheye=True)
     assert c[0, 0] == 0.0 and c[0, 1] == 0.0
+
+
+# ---- delayed stereo matching (DELAYED_STEREO_MATCHING build) ------------------------------------
+def _kp(x, y, octave=0):
+    k = np.zeros(1, KP_DTYPE)
+    k["x"], k["y"], k["octave"] = x, y, octave
+    return k[0]
+
+
+def test_stereo_online_known_answers(oracle):
+    """Hand-made frame: which keypoints an online / offline call touches, the narrowed disparity
+    window, the persistent mvDistIdx and the median cut over old and new entries."""
+    sf = oracle.tables()["scale"]
+    d = np.zeros((6, 32), np.uint8)
+    kl = np.array([_kp(100, 50), _kp(200, 60), _kp(300, 70), _kp(400, 80), _kp(500, 90), _kp(90, 600)], KP_DTYPE)
+    # right keypoint i sits 10 + i px left of left keypoint i, same row
+    kr = np.array([_kp(90, 50), _kp(189, 60), _kp(288, 70), _kp(387, 80), _kp(486, 90), _kp(75, 600)], KP_DTYPE)
+    dl = d.copy()
+    dr = d.copy()
+    dr[1, 0] = 0x0F          # distance 4
+    dr[2, :5] = 0xFF         # distance 40
+    dr[3, 0] = 0x01          # distance 1
+    f = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, 40.0, 0.1, 0.0)
+    assert (f.mvuRight[:6] == -1).all() and (f.mvDepth[:6] == -1).all() and not f.mvStereoMatched.any()
+    # online: only keypoints with a map point (0, 1, 4); prior of keypoint 4 excludes its true disparity 14
+    f.has_mappoint[:6] = [1, 1, 0, 0, 1, 1]
+    f.prior_disp[:6] = [10.0, -1.0, 0, 0, 80.0, 15.0]       # keypoint 4: window [30, 130)
+    nm = f.ComputeStereoMatches_Undistorted(True)
+    assert list(f.mvStereoMatched[:6]) == [1, 1, 0, 0, 1, 1]
+    assert nm == 3                                         # 0, 1, 4 reached the scan; 5 lies below the image
+    assert f.mvuRight[0] == 90 and f.mvuRight[1] == 189 and f.mvuRight[4] == -1
+    assert f.mvDepth[0] == np.float32(40.0) / np.float32(10.0)
+    assert list(f.listed_dist()[:6]) == [0, 4, -1, -1, -1, -1]
+    # offline: the rest (2, 3); median over dists {0, 1, 4, 40} = element 2 = 4 -> cut at 8.4 drops keypoint 2
+    nm = f.ComputeStereoMatches_Undistorted(False)
+    assert nm == 2 - 1
+    assert f.mvStereoMatched[:6].all()
+    assert f.mvuRight[3] == 387 and f.mvuRight[2] == -1 and f.mvDepth[2] == -1
+    assert list(f.listed_dist()[:6]) == [0, 4, 40, 1, -1, -1]
+    assert f.mvuRight[0] == 90 and f.mvuRight[1] == 189    # earlier matches below the cut survive
+
+
+def test_stereo_one_point_known_answers(oracle):
+    sf = oracle.tables()["scale"]
+    kl = np.array([_kp(100, 50, 2), _kp(200, 60, 2)], KP_DTYPE)
+    kr = np.array([_kp(90, 50, 4), _kp(95, 51, 3), _kp(60, 60, 2)], KP_DTYPE)
+    dl = np.zeros((2, 32), np.uint8)
+    dr = np.zeros((3, 32), np.uint8)
+    dr[1, 0] = 0x03
+    f = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, 40.0, 0.1, 0.0)
+    assert not f.ComputeStereoMatch_OnePoint(0, 75, 0.0, 400.0)      # no map point
+    f.has_mappoint[:2] = 1
+    # right keypoint 0 (octave 4) is outside levelL +- 1; keypoint 1 (octave 3, distance 2) wins
+    assert f.ComputeStereoMatch_OnePoint(0, 75, 0.0, 400.0)
+    assert f.best_idx[0] == 1 and f.best_dist[0] == 2 and f.mvuRight[0] == 95
+    assert not f.ComputeStereoMatch_OnePoint(0, 75, 0.0, 400.0)      # already matched
+    # disparity 140 outside [0, 100): scanned, nothing stored
+    assert not f.ComputeStereoMatch_OnePoint(1, 75, 0.0, 100.0)
+    assert f.mvuRight[1] == -1 and f.mvStereoMatched[1]
+    assert not f.ComputeStereoMatch_OnePoint(5, 75, 0.0, 100.0) and not f.ComputeStereoMatch_OnePoint(-1, 75, 0.0, 1.0)
+
+
+def test_stereo_offline_equals_one_piece_search(oracle, euroc_left, euroc_right):
+    """Without map points one offline call is the search + finish pair the other tests use."""
+    kl, dl = oracle.extract(euroc_left)
+    kr, dr = oracle.extract(euroc_right)
+    sf = oracle.tables()["scale"]
+    mbf, mb = 47.9, 0.11
+    maxD = float(np.float32(mbf) / np.float32(mb))
+    f = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, mbf, mb, 0.0)
+    nm = f.ComputeStereoMatches_Undistorted(False)
+    bi, bd = oracle.stereo_search(kl, dl, kr, dr, sf, 480, 0.0, maxD, 0.0)
+    n2, ur, dp = oracle.stereo_finish(kl, kr, bi, bd, mbf, 0.0, maxD)
+    assert nm == n2 and np.array_equal(f.mvuRight[:len(kl)], ur) and np.array_equal(f.mvDepth[:len(kl)], dp)
+    scanned = bi >= 0
+    assert np.array_equal(f.best_idx[:len(kl)][scanned], bi[scanned])
+
+
+# ---- cos / sin of the descriptor rotation --------------------------------------------------------
+def test_trig_modes_agree_on_descriptors(euroc_left, euroc_right):
+    """The reference calls libm's cosf / sinf; the GPU evaluates correctly rounded values.  They differ
+    in the last bit for about 0.1 % of the angles; a descriptor only changes when a rotated coordinate
+    lies that close to a rounding boundary.  Measure it on real and synthetic frames."""
+    from oracle_lib import Oracle
+    from orb_slam_amd.synth import synthetic_frame
+    a, b = Oracle(trig="rounded"), Oracle(trig="libm")
+    c, s, n = a.count_trig_differences(0, 997)
+    assert n > 1_000_000 and c + s < 0.005 * n          # rare, and never more than one ulp apart by construction
+    total = differ = 0
+    for img in [euroc_left, euroc_right] + [synthetic_frame(752, 480, 1234 + i) for i in range(6)]:
+        ka, da = a.extract(img)
+        kb, db = b.extract(img)
+        assert np.array_equal(ka, kb)
+        total += len(da)
+        differ += int((da != db).any(axis=1).sum())
+    assert total > 7000
+    assert differ <= 0.001 * total, (differ, total)
+
+
+def test_trig_difference_count_is_recorded():
+    """The number written in oracle/orb_oracle.h is what this libm gives on a 1/64 sample"""
+    from oracle_lib import Oracle
+    o = Oracle()
+    c, s, n = o.count_trig_differences(0, 64)
+    assert n == (0x43B40000 + 63) // 64
+    # full count on glibc 2.35: 483 807 (cos) and 1 001 902 (sin) of 1 135 869 952
+    assert abs(c * 64 - 483807) < 0.1 * 483807 and abs(s * 64 - 1001902) < 0.1 * 1001902

@@ -115,8 +115,9 @@ def test_bench_match_8000_x_100000():
     Q, T = 8000, 100000
     q = random_descriptors(Q, 5)
     t = map_descriptors(T, q, seed=99, planted=0.10)
-    t[70000] = t[123]            # exact duplicates far apart: the lower index must win across the split
-    q[17] = t[123]
+    q[17:20] = random_descriptors(3, 6)      # fresh queries: no planted copy of them exists yet
+    t[123] = q[17]
+    t[70000] = q[17]             # exact duplicates far apart: the lower index must win across the split
     t[99999] = q[18]             # best match in the very last train row
     t[0] = q[19]
     dev = torch.device("cuda", 0)

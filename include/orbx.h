@@ -152,6 +152,21 @@ int orbx_match_bruteforce_device(orbx_ctx *ctx, const uint32_t *d_q, int Q, int 
                                  const uint32_t *d_t, int T, int t_stride, const int32_t *d_nt, int nbatch,
                                  int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist);
 
+/* The same search without any allocation.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory -- code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  orbx_match_bruteforce_device keeps the per-split partial
+ * results of a large search in a buffer it allocates (and grows) on demand; this entry point keeps
+ * them in a static device array of 4 MiB that every GPU the library runs on holds until the
+ * process ends, and calls no hipMalloc / hipFree.  Problems whose partial results need more
+ * (nbatch * tsplit * q_stride * 8 bytes; 8000 x 100 000 needs 3.9 MiB, 128 x 1000 x 1000 needs 2.9 MiB,
+ * 300 x 1000 x 1000 would need 4.6 MiB)
+ * are rejected with ORBX_ERR_CAPACITY and a message naming both sizes.  All calls on one GPU share
+ * that GPU's array: calls that overlap in time on one GPU (different streams or contexts) race;
+ * calls ordered on one stream do not, and nothing carries over between calls. */
+int orbx_match_bruteforce_device_static(orbx_ctx *ctx, const uint32_t *d_q, int Q, int q_stride, const int32_t *d_nq,
+                                        const uint32_t *d_t, int T, int t_stride, const int32_t *d_nt, int nbatch,
+                                        int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist);
+
 /* Windowed search over per-query candidate lists in CSR form (cand_off[Q+1],
  * cand_idx[]): best / second-best distance, index and octave exactly as the
  * scan at src/ORBmatcher.cc:186-225 leaves them (first candidate in list order

@@ -53,6 +53,7 @@ SIGNATURES = {
     "orbx_hamming": (_i, [_vp, _vp]),
     "orbx_match_bruteforce": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_match_bruteforce_device": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "orbx_match_bruteforce_device_static": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_match_windowed": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "orbx_hamming_csr": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp]),
     "orbx_stereo_match": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _ip]),

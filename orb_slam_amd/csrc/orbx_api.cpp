@@ -62,6 +62,7 @@ struct orbx_ctx {
     std::vector<hipEvent_t> ev_up;      // one per chunk of a pipelined host-fed batch
     bool aux_busy = false;              // uploads were queued on aux_stream since the last finish()
     std::string err;
+    uint32_t* static_scratch = nullptr;   // this device's copy of the static scratch array (orbx_match.hip)
 
     // geometry of the current frame size
     int gw = 0, gh = 0;
@@ -465,6 +466,11 @@ int orbx_create(orbx_ctx** out, int nfeatures, float scaleFactor, int nlevels, i
         return ORBX_ERR_HIP;
     }
     c->stream = c->own_stream;
+    {
+        hipError_t se;
+        c->static_scratch = match_static_scratch(device, &se);   // nullptr: only the _static entry point is affected
+        if (!c->static_scratch) (void)hipGetLastError();
+    }
     int taps[7];
     gauss7_taps(taps);
     if (upload_constant_tables(taps, c->p.umax, c->stream) != 0) {
@@ -891,6 +897,34 @@ int orbx_match_bruteforce_device(orbx_ctx* c, const uint32_t* d_q, int Q, int q_
         }
     }
     launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->partial.as<uint32_t>(),
+                            d_best_idx, d_best_dist, d_second_dist, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    return ORBX_OK;
+}
+
+int orbx_match_bruteforce_device_static(orbx_ctx* c, const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
+                                        const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
+                                        int32_t* d_best_idx, int32_t* d_best_dist, int32_t* d_second_dist)
+{
+    if (!c) return ORBX_ERR_INVALID;
+    if (!d_q || !d_best_idx || !d_best_dist || !d_second_dist) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (Q < 0 || T < 0 || nbatch < 1 || nbatch > 65535 || q_stride < Q || (t_stride != 0 && t_stride < T))
+        return fail(c, ORBX_ERR_INVALID, "bad sizes");
+    if (T > 0 && !d_t) return fail(c, ORBX_ERR_INVALID, "null train set");
+    if (T >= (1 << 22)) return fail(c, ORBX_ERR_UNSUPPORTED, "train set of 2^22 descriptors or more");
+    if (q_stride == 0) return ORBX_OK;
+    HIPCHECK(c, hipSetDevice(c->device));
+    if (!c->static_scratch) return fail(c, ORBX_ERR_HIP, "the static scratch array of this device could not be located at orbx_create");
+    const int tsplit = match_bruteforce_tsplit(q_stride, T, nbatch);
+    const size_t need = tsplit > 1 ? (size_t)nbatch * tsplit * q_stride * 8 : 0;
+    if (need > kMatchStaticScratchBytes) {
+        c->err = "problem needs " + std::to_string(need) + " bytes of scratch; the static scratch of "
+                 "orbx_match_bruteforce_device_static holds " + std::to_string(kMatchStaticScratchBytes) +
+                 " (use orbx_match_bruteforce_device, or fewer batches per call)";
+        return ORBX_ERR_CAPACITY;
+    }
+    // every slot k_match_merge reads is written by this call's sweep first: nothing to clear
+    launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->static_scratch,
                             d_best_idx, d_best_dist, d_second_dist, c->stream);
     HIPCHECK(c, hipGetLastError());
     return ORBX_OK;

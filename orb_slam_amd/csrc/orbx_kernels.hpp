@@ -57,6 +57,9 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
                              int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
                              int32_t* d_second_dist, hipStream_t s);
 int match_bruteforce_tsplit(int Q, int T, int nbatch);
+// static device scratch of the entry point that allocates nothing (one array per GPU, orbx_match.hip)
+constexpr size_t kMatchStaticScratchBytes = 4u << 20;
+uint32_t* match_static_scratch(int device, hipError_t* err);
 void launch_match_windowed(const uint32_t* d_q, int Q, const uint32_t* d_t, const int32_t* d_off,
                            const int32_t* d_idx, const int32_t* d_toct, int32_t* d_best_idx, int32_t* d_best_dist,
                            int32_t* d_second_dist, int32_t* d_best_lvl, int32_t* d_second_lvl, hipStream_t s);

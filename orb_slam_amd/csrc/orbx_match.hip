@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <mutex>
 
 #include "../../include/orbx.h"
 #include "orbx_common.hpp"
@@ -381,6 +382,37 @@ void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const i
 {
     if (Q <= 0) return;
     hipLaunchKernelGGL(k_hamming_csr, dim3((Q + 255) / 256), dim3(256), 0, s, d_q, Q, d_t, d_off, d_idx, d_out);
+}
+
+// ---------------------------------------------------------------------------
+// Scratch for the entry point that allocates nothing (orbx_match_bruteforce_device_static): the
+// per-split (best, second) keys of k_match_bruteforce[_mfma] that k_match_merge combines.  Every GPU the
+// library runs on holds its own copy of this array, at its own address, until the process ends.
+// The name below is only a host-side handle: kernels get the address hipGetSymbolAddress reports
+// for the current device.
+// ---------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[kMatchStaticScratchBytes];
+
+namespace {
+std::mutex g_scratch_mutex;
+constexpr int kMaxScratchDevices = 64;
+void* g_scratch_ptr[kMaxScratchDevices] = {};
+}
+
+// `device` must be the current device.  Returns the device address of this GPU's scratch array
+// (looked up once per device), or nullptr with *err set.
+uint32_t* match_static_scratch(int device, hipError_t* err)
+{
+    *err = hipSuccess;
+    if (device < 0 || device >= kMaxScratchDevices) { *err = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) { *err = e != hipSuccess ? e : hipErrorInvalidSymbol; return nullptr; }
+        g_scratch_ptr[device] = p;
+    }
+    return static_cast<uint32_t*>(g_scratch_ptr[device]);
 }
 
 // ---------------------------------------------------------------------------

@@ -47,6 +47,12 @@ class ORBmatcher:
             self._ctx, ptr(d_q), Q, q_stride, ptr(d_nq), ptr(d_t), T, t_stride, ptr(d_nt), nbatch,
             ptr(d_bi), ptr(d_bd), ptr(d_sd)))
 
+    def match_bruteforce_device_static(self, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, d_bi, d_bd, d_sd):
+        """the same search on the library's static device scratch: allocates nothing"""
+        check(self._lib, self._ctx, self._lib.orbx_match_bruteforce_device_static(
+            self._ctx, ptr(d_q), Q, q_stride, ptr(d_nq), ptr(d_t), T, t_stride, ptr(d_nt), nbatch,
+            ptr(d_bi), ptr(d_bd), ptr(d_sd)))
+
     def match_windowed(self, q, t, cand_off, cand_idx, t_octave=None):
         q, t = _desc(q), _desc(t)
         Q, T = len(q), len(t)

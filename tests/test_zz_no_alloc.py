@@ -1,0 +1,60 @@
+"""The entry point that allocates nothing (orbx_match_bruteforce_device_static) against
+orbx_match_bruteforce_device: same results, two calls in a row, the second on a smaller input."""
+import numpy as np
+import pytest
+
+from orb_slam_amd.synth import random_descriptors, map_descriptors
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(m, ex, torch, q, t, nb=1):
+    dev = torch.device("cuda", 0)
+    Q, T = q.shape[-2], t.shape[-2]
+    dq, dt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
+    shape = (nb, Q) if nb > 1 else (Q,)
+    ref = [torch.full(shape, -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    got = [torch.full(shape, -9, dtype=torch.int32, device=dev) for _ in range(3)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    m.match_bruteforce_device(dq, Q, Q, None, dt, T, T, None, nb, *ref)
+    m.match_bruteforce_device_static(dq, Q, Q, None, dt, T, T, None, nb, *got)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    return [g.cpu().numpy() for g in got], [r.cpu().numpy() for r in ref]
+
+
+def test_static_scratch_entry_point_matches_allocating_one():
+    torch = pytest.importorskip("torch")
+    from orb_slam_amd import ORBextractor, ORBmatcher, OrbxError
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex)
+    # first call: the benchmark's 8000 x 100 000 (64 splits, 3.9 MiB of partial results)
+    q = random_descriptors(8000, 5)
+    t = map_descriptors(100000, q, seed=99)
+    t[70000] = t[123]
+    got, ref = _both(m, ex, torch, q, t)
+    for g, r, name in zip(got, ref, ("best_idx", "best_dist", "second_dist")):
+        assert np.array_equal(g, r), name
+    assert (ref[1] < 40).sum() > 1000          # the planted matches were found
+    # second call, smaller: stale partial results of the first call must not leak in
+    q2 = random_descriptors(3000, 7)
+    t2 = map_descriptors(20000, q2, seed=8)
+    got, ref = _both(m, ex, torch, q2, t2)
+    for g, r, name in zip(got, ref, ("best_idx", "best_dist", "second_dist")):
+        assert np.array_equal(g, r), name
+    # third: batched and tiny (one split: no scratch at all)
+    rng = np.random.default_rng(3)
+    qb = rng.integers(0, 256, (6, 500, 32), dtype=np.uint8)
+    tb = rng.integers(0, 256, (6, 700, 32), dtype=np.uint8)
+    got, ref = _both(m, ex, torch, qb, tb, nb=6)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    # beyond the static scratch: a clear refusal, nothing launched
+    dev = torch.device("cuda", 0)
+    big_q = torch.zeros((300, 1000, 32), dtype=torch.uint8, device=dev)
+    big_t = torch.zeros((300, 1000, 32), dtype=torch.uint8, device=dev)
+    outs = [torch.zeros((300, 1000), dtype=torch.int32, device=dev) for _ in range(3)]
+    with pytest.raises(OrbxError) as ei:
+        m.match_bruteforce_device_static(big_q, 1000, 1000, None, big_t, 1000, 1000, None, 300, *outs)
+    assert ei.value.code == -4 and "static scratch" in str(ei.value)
+    ex.close()

@@ -79,3 +79,13 @@ def test_cpp_host_class_builds_against_the_abi():
     d = os.path.join(ROOT, "tests", "cpp")
     subprocess.check_call(["make", "-C", d, "host_extract"])
     assert os.path.exists(os.path.join(d, "host_extract"))
+
+
+def test_adapter_header_compiles_against_cv_stand_in():
+    """include/orbx_adapter.hpp -- ORB_SLAM2::ORBextractor with cv::Mat / cv::KeyPoint signatures -- and a caller
+    shaped like the reference's Frame (src/Frame.cc:553-559, :1089, :1111, :187-190) compile as C++11 against the
+    minimal cv stand-in in tests/cpp/mini_cv and link against liborbx.so."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", d, "adapter_frame"])
+    assert os.path.exists(os.path.join(d, "adapter_frame"))

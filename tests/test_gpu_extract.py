@@ -378,6 +378,23 @@ def test_cpp_host_program(oracle, euroc_left, tmp_path):
     assert buf[-1] == top[top.shape[0] // 2, top.shape[1] // 2]
 
 
+def test_cpp_adapter_program(euroc_left, tmp_path):
+    """The drop-in class of include/orbx_adapter.hpp, driven like the reference's Frame drives its extractors:
+    same keypoints / descriptors as the OpenCV-free host class, level views that are regions of interest inside
+    their REFLECT_101-bordered planes, ComputePyramid on its own, empty-image behaviour."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "adapter_frame")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "adapter_frame"])
+    raw = tmp_path / "img.raw"
+    euroc_left.tofile(raw)
+    p = subprocess.run([exe, str(raw), "752", "480"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=100)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "adapter ok: 1009 keypoints, 8 levels" in p.stdout.decode()
+
+
 def test_4k_8000_features():
     """3840x2160, 8000 features: 1737-node quadtree (LDS above 64 KB), > 4096 candidates per
     level (keys beyond the register-resident ones), 8820 cells on level 0."""

@@ -21,7 +21,8 @@ class OrbxError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "liborbx.so")
+    # ORBX_LIBRARY: another build of the same library (diagnostic builds, A/B comparisons)
+    return os.environ.get("ORBX_LIBRARY") or os.path.join(_HERE, "lib", "liborbx.so")
 
 
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float

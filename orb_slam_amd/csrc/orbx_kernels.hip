@@ -392,6 +392,60 @@ __device__ __forceinline__ int fast_score_lds(const uint8_t* c, int pitch)
     return max(v - mnmx, mxmn - v) - 1;
 }
 
+// The same score for two pixels at once: ring pixel k of pixel A in the low and of pixel B in the high
+// 16 bits of one register, and the 3-input packed minimum / maximum of gfx950.  Those are half-float
+// instructions; on the bit patterns 0x0000 .. 0x00ff (positive denormals, kept as they are: the kernels
+// run with 16-bit denormals enabled) float order is integer order, and a minimum / maximum returns one of
+// its inputs unchanged.  Returns max(S, 0) per half (a negative S is never a corner).
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ us2_t pk_max3_u8(us2_t a, us2_t b, us2_t c)
+{
+    us2_t r;
+    asm("v_pk_maximum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ us2_t pk_min3_u8(us2_t a, us2_t b, us2_t c)
+{
+    us2_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ us2_t fast_score2_lds(const uint8_t* ca, const uint8_t* cb, int pitch)
+{
+    const int off[16] = {3 * pitch, 3 * pitch + 1, 2 * pitch + 2, pitch + 3, 3, -pitch + 3, -2 * pitch + 2, -3 * pitch + 1,
+                         -3 * pitch, -3 * pitch - 1, -2 * pitch - 2, -pitch - 3, -3, pitch - 3, 2 * pitch - 2, 3 * pitch - 1};
+    us2_t p[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) p[k] = us2_t{ca[off[k]], cb[off[k]]};
+    const us2_t v = {ca[0], cb[0]};
+    us2_t mx3[16], mn3[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mx3[k] = pk_max3_u8(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+        mn3[k] = pk_min3_u8(p[k], p[(k + 1) & 15], p[(k + 2) & 15]);
+    }
+    us2_t mx9[16], mn9[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mx9[k] = pk_max3_u8(mx3[k], mx3[(k + 3) & 15], mx3[(k + 6) & 15]);
+        mn9[k] = pk_min3_u8(mn3[k], mn3[(k + 3) & 15], mn3[(k + 6) & 15]);
+    }
+    // min over the 16 arc maxima, max over the 16 arc minima: 16 -> 6 -> 2 -> 1
+    us2_t a[6], b[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        a[k] = pk_min3_u8(mx9[3 * k], mx9[3 * k + 1], mx9[3 * k + 2]);
+        b[k] = pk_max3_u8(mn9[3 * k], mn9[3 * k + 1], mn9[3 * k + 2]);
+    }
+    a[5] = mx9[15];
+    b[5] = mn9[15];
+    const us2_t mnmx = pk_min3_u8(pk_min3_u8(a[0], a[1], a[2]), pk_min3_u8(a[3], a[4], a[5]), a[5]);
+    const us2_t mxmn = pk_max3_u8(pk_max3_u8(b[0], b[1], b[2]), pk_max3_u8(b[3], b[4], b[5]), b[5]);
+    const us2_t one = {1, 1};
+    const us2_t sc = __builtin_elementwise_max(__builtin_elementwise_sub_sat(v, mnmx), __builtin_elementwise_sub_sat(mxmn, v));
+    return __builtin_elementwise_sub_sat(sc, one);
+}
+
 // inclusive scan over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside each row of
 // 16 lanes (row_shr 1, 2, 4, 8 shifting zeros in), then the last lane of rows 0 and 2 is added to
 // rows 1 and 3 (row_bcast15), then lane 31 to rows 2 and 3 (row_bcast31)
@@ -409,7 +463,6 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 // four pixels at a time for the FAST pretest: a dword of pixels split into its
 // even and odd bytes as pairs of 16-bit lanes, so that packed 16-bit min / max / saturating subtract
 // work on two pixels per instruction
-typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2_t even_bytes(uint32_t x) { return __builtin_bit_cast(us2_t, x & 0x00ff00ffu); }
 __device__ __forceinline__ us2_t odd_bytes(uint32_t x) { return __builtin_bit_cast(us2_t, __builtin_amdgcn_perm(0u, x, 0x0c030c01u)); }
 // the compiler turns min(x, 1) into compare + select + repack; keep it one instruction (b: both halves in an SGPR)
@@ -448,6 +501,20 @@ constexpr int kFastTileFixed = 48, kFastScoreFixed = 40;   // pitches of the spe
 // call in the reference).  Output: the cell's keypoints in row-major order, packed
 // (y_local << 16 | x_local << 8 | score), and their count.
 // ---------------------------------------------------------------------------
+// Optional per-section cycle counts of the per-cell FAST code (diagnostic builds only:
+// make EXTRA=-DORBX_FAST_PROFILE): summed over all cells into g_fast_prof, read with orbx_debug_fast_profile.
+#ifdef ORBX_FAST_PROFILE
+__device__ unsigned long long g_fast_prof[16];
+#define PROF_DECL unsigned long long prof_t = __builtin_readcyclecounter(), prof_acc[6] = {0, 0, 0, 0, 0, 0}
+#define PROF_MARK(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); prof_acc[k] += now_ - prof_t; prof_t = now_; } while (0)
+#define PROF_COUNT(k, v) do { if (threadIdx.x == 0) atomicAdd(&g_fast_prof[k], (unsigned long long)(v)); } while (0)
+#define PROF_FLUSH() do { if (threadIdx.x == 0) { for (int k_ = 0; k_ < 6; k_++) atomicAdd(&g_fast_prof[k_], prof_acc[k_]); atomicAdd(&g_fast_prof[6], 1ull); } } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(k)
+#define PROF_COUNT(k, v)
+#define PROF_FLUSH()
+#endif
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // TPC / SPC: compile-time tile and score pitches (0 = take them from fl): with constants every
 // ring pixel is an immediate offset from one LDS address.
@@ -471,6 +538,7 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     }
     const uint8_t* src = pyr + (size_t)f * g.pyr_frame_bytes + fc.src_off;
     const int th = ch + 6;
+    PROF_DECL;
     // Tile load: 16 lanes per tile row (32 when the pitch is not the compiled-in one), whole rows per
     // step, so that every address is the previous one plus a constant.  A denser packing of the
     // lanes needs fewer loads but a division per dword, and this kernel is bound by instruction issue.
@@ -494,6 +562,7 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         for (int i = lane; i < ((ch + 2) * SP + 15) >> 4; i += 64) sc128[i] = make_uint4(0u, 0u, 0u, 0u);
     }
     WAVE_SYNC();
+    PROF_MARK(0);
 
     const uint8_t* tile8 = reinterpret_cast<const uint8_t*>(s_tile);
     const int npix = cw * ch;
@@ -506,23 +575,61 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     // Queue entry: pixel index (12 bits) | 0x8000 if the pretest value exceeds iniThFAST as well.
     const int qcap = fl.queue_cap;
     bool flushed = false;
-    auto score_entries = [&](int lo, int hi) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // Scores of the queue entries [lo, hi) into the score tile.  More than 64 entries go two per lane through
+    // the packed form (entries q and q + 64 of a round of 128).  With `compact`, the entries whose score is a
+    // corner score (>= minThFAST) are rewritten, in order, to the front of the queue and their number is
+    // returned: the maxima search then visits only those (most pretest survivors score nothing).
+    auto score_entries = [&](int lo, int hi, bool compact) -> int {
+        int kept = 0;
+        if (hi - lo > 64) {
+            for (int q0 = lo; q0 < hi; q0 += 128) {
+                const int qa = q0 + lane, qb = qa + 64;
+                const bool va = qa < hi, vb = qb < hi;
+                const int ia = s_queue[va ? qa : lo] & 0x0fff;
+                const int ib = vb ? (s_queue[qb] & 0x0fff) : ia;
+                const int pya = (int)(__umul24((uint32_t)ia, rcp_cw) >> 18), pxa = ia - __mul24(pya, cw);
+                const int pyb = (int)(__umul24((uint32_t)ib, rcp_cw) >> 18), pxb = ib - __mul24(pyb, cw);
+                const us2_t sc = fast_score2_lds(tile8 + (pya + 3) * TP + pxa + 3 + ox, tile8 + (pyb + 3) * TP + pxb + 3 + ox, TP);
+                const int sa = sc.x, sb = sc.y;
+                const bool ka = va && sa >= t && sa > 0, kb = vb && sb >= t && sb > 0;
+                if (va) s_score[(pya + 1) * SP + pxa + 1] = (uint8_t)(ka ? sa : 0);
+                if (vb) s_score[(pyb + 1) * SP + pxb + 1] = (uint8_t)(kb ? sb : 0);
+                if (compact) {
+                    const unsigned long long ba = __ballot(ka), bb = __ballot(kb);
+                    if (ka) s_queue[kept + __popcll(ba & below)] = (uint16_t)ia;
+                    kept += __popcll(ba);
+                    if (kb) s_queue[kept + __popcll(bb & below)] = (uint16_t)ib;
+                    kept += __popcll(bb);
+                }
+            }
+            return kept;
+        }
         for (int q0 = lo; q0 < hi; q0 += 64) {
             const int q = q0 + lane;
-            if (q < hi) {
-                const int i = s_queue[q] & 0x0fff;
+            const bool valid = q < hi;
+            int i = 0;
+            bool keep = false;
+            if (valid) {
+                i = s_queue[q] & 0x0fff;
                 const int py = (int)(__umul24((uint32_t)i, rcp_cw) >> 18), px = i - __mul24(py, cw);
                 const int s = fast_score_lds(tile8 + (py + 3) * TP + px + 3 + ox, TP);
-                s_score[(py + 1) * SP + px + 1] = (uint8_t)((s >= t && s > 0) ? s : 0);
+                keep = s >= t && s > 0;
+                s_score[(py + 1) * SP + px + 1] = (uint8_t)(keep ? s : 0);
+            }
+            if (compact) {
+                const unsigned long long bal = __ballot(keep);
+                if (keep) s_queue[kept + __popcll(bal & below)] = (uint16_t)i;
+                kept += __popcll(bal);
             }
         }
+        return kept;
     };
     auto score_queue = [&]() {
         WAVE_SYNC();
-        score_entries(0, nq);
+        score_entries(0, nq, false);
         WAVE_SYNC();
     };
-    const unsigned long long below = (1ull << lane) - 1ull;
     {
         // Pretest, four horizontally adjacent pixels per lane: lane = (row r of the round, group c of
         // 4 columns), lpr = ceil(cw / 4) lanes per row, R = 64 / lpr rows per round.  Five dword reads
@@ -542,9 +649,10 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         const int nv = cw - c4;                             // valid pixels of this lane's group: columns < cw
         const uint32_t colE = (nv > 0 ? 0x0000ffffu : 0u) | (nv > 2 ? 0xffff0000u : 0u);
         const uint32_t colO = (nv > 1 ? 0x0000ffffu : 0u) | (nv > 3 ? 0xffff0000u : 0u);
-        const us2_t ts2 = {(unsigned short)ts, (unsigned short)ts};
+        const us2_t ts2 = {(unsigned short)(0x7fff - ts), (unsigned short)(0x7fff - ts)};      // ts <= 255
         const uint32_t t32 = (uint32_t)t | ((uint32_t)t << 16);
-        const uint32_t thrE = t32 | ~colE, thrO = t32 | ~colO;      // per-lane thresholds, 0xffff where the column is invalid
+        // per-lane thresholds, 0xffff where the column is invalid; lanes past the last whole row of a round never take part
+        const uint32_t thrE = r < R ? (t32 | ~colE) : 0xffffffffu, thrO = r < R ? (t32 | ~colO) : 0xffffffffu;
         const uint32_t one2 = 0x00010001u;
         const int step_w = __mul24(R, TPW);
         for (int y0 = 0; y0 < ch; y0 += R) {
@@ -562,15 +670,22 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
             const us2_t mO = compass2(odd_bytes(av), odd_bytes(a0), odd_bytes(a8), odd_bytes(a4), odd_bytes(a12));
             // invalid pixels (columns past the cell, rows past it in the last round) get the threshold 0xffff:
             // their saturated difference is 0
-            const bool row_ok = row < ch;
-            const us2_t tE = __builtin_bit_cast(us2_t, row_ok ? thrE : 0xffffffffu), tO = __builtin_bit_cast(us2_t, row_ok ? thrO : 0xffffffffu);
+            // only the last round can hold rows past the cell (wave-uniform test: the other rounds skip the selects)
+            uint32_t tEw = thrE, tOw = thrO;
+            if (y0 + R > ch) {
+                const bool row_ok = row < ch;
+                tEw = row_ok ? thrE : 0xffffffffu;
+                tOw = row_ok ? thrO : 0xffffffffu;
+            }
+            const us2_t tE = __builtin_bit_cast(us2_t, tEw), tO = __builtin_bit_cast(us2_t, tOw);
             const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, tE));
             const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, tO));
             const us2_t cE = pk_min_u16(__builtin_bit_cast(us2_t, dE), one2);          // 1 per survivor
             const us2_t cO = pk_min_u16(__builtin_bit_cast(us2_t, dO), one2);
-            // entry = index + 0x8000 * (pretest value above iniThFAST): one packed multiply-add per pair
-            const us2_t eE = pk_mad_u16(pk_min_u16(__builtin_elementwise_sub_sat(mE, ts2), one2), 0x80008000u, idxE);
-            const us2_t eO = pk_mad_u16(pk_min_u16(__builtin_elementwise_sub_sat(mO, ts2), one2), 0x80008000u, idxO);
+            // entry = index | 0x8000 if the pretest value exceeds iniThFAST: m + (0x7fff - ts) carries into bit 15
+            // exactly then (m <= 255), and the index stays below 0x1000
+            const us2_t eE = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mE + ts2) & 0x80008000u) | idxE);
+            const us2_t eO = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mO + ts2) & 0x80008000u) | idxO);
             const uint32_t both = __builtin_bit_cast(uint32_t, cE) + __builtin_bit_cast(uint32_t, cO);
             const int cnt = (int)((both & 0xffffu) + (both >> 16));
             const int incl = wave_incl_scan(cnt);
@@ -591,6 +706,8 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     }
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
     int base = 0;
+    PROF_MARK(1);
+    PROF_COUNT(8, nq);
     if (!flushed && nq > 64) {       // up to 64 survivors are one round of scores anyway
         // Only pixels whose pretest value exceeds iniThFAST (the score is below the pretest value) can be
         // corners of the reference's first cv::FAST call, and a neighbour that is not among them cannot
@@ -610,7 +727,7 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         }
         if (ns > 0 && nq + ns <= qcap) {
             WAVE_SYNC();
-            score_entries(nq, nq + ns);
+            score_entries(nq, nq + ns, false);
             WAVE_SYNC();
             for (int q0 = nq; q0 < nq + ns; q0 += 64) {
                 const int q = q0 + lane;
@@ -634,13 +751,25 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
                 }
                 base += __popcll(bal);
             }
+            PROF_COUNT(9, ns);
             if (base > 0) {
                 if (lane == 0) *count_out = min(base, cell_cap);
+                PROF_MARK(2);
+                PROF_COUNT(7, 1);
+                PROF_FLUSH();
                 return;
             }
         }
     }
-    score_queue();
+    PROF_MARK(2);
+    if (flushed) score_queue();
+    else {
+        // the entries that scored replace the queue; positions written are never ahead of positions still to be read
+        WAVE_SYNC();
+        nq = score_entries(0, nq, true);
+        WAVE_SYNC();
+    }
+    PROF_MARK(3);
     // Strict 8-neighbour maxima.  Maxima that reach the initial threshold are emitted right
     // here, in queue (= row-major) order: if the cell has any, they are its whole result
     // (the first cv::FAST call of the reference found something).  Only a cell without one
@@ -724,7 +853,23 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         }
     }
     if (lane == 0) *count_out = min(base, cell_cap);
+    PROF_MARK(4);
+    PROF_FLUSH();
 }
+
+#ifdef ORBX_FAST_PROFILE
+}  // namespace orbx
+extern "C" int orbx_debug_fast_profile(unsigned long long* out16, int reset)
+{
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(orbx::g_fast_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(orbx::g_fast_prof), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+namespace orbx {
+#endif
 
 // One wavefront = one workgroup = one cell.  (Several cells per wavefront to save workgroup dispatches
 // measured slower: the dispatch of one cell overlaps the arithmetic of the others.)

@@ -67,7 +67,7 @@ struct orbx_ctx {
     // geometry of the current frame size
     int gw = 0, gh = 0;
     FrameGeom g;
-    SlideMap blur_map;
+    SlideMap blur_map, blur_map_batch;   // row bands of the blur: short for a few frames (latency), longer for batches
     FastLds fast_lds;
     int mk_w = -1, mk_h = -1, mk_val = 0;   // last orbx_max_keypoints answer
     // pinned staging arena of the host-buffer entry points
@@ -178,6 +178,9 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     // short bands: the kernel is bound by the latency of its dependent row groups, and many short
     // wavefronts hide it better than few long ones (measured optimum 12 rows, 6 of warm-up included)
     make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 12, c->blur_map);
+    // in a batch the FAST wavefronts of the same launch hide the blur's load latency, and every band pays six
+    // warm-up rows of horizontal sums: longer bands there (measured: 24 rows, 2 % off the fused launch)
+    make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 24, c->blur_map_batch);
     make_fast_lds(c->g, c->fast_lds);
     c->gw = w;
     c->gh = h;
@@ -274,7 +277,8 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     const bool fused = (!e_fuse || nframes <= atoi(e_fuse)) && !overlap && g.ncells > 0;
     t0(ST_FAST, s);
     if (fused)
-        launch_fast_blur(pyr, blur, g, c->fast_lds, c->blur_map, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
+        launch_fast_blur(pyr, blur, g, c->fast_lds, nframes >= 32 ? c->blur_map_batch : c->blur_map, c->fast_cells.as<FastCell>(),
+                         cell_cand, cell_count, nframes, s);
     else
         launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
     t1(ST_FAST, s);

@@ -908,7 +908,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
 // the other by memory (measured: the fused launch takes what the two took, and the descriptor kernel
 // that follows finds more of the blurred planes in cache).
 template <int TPC = 0, int SPC = 0>
-__global__ __launch_bounds__(64) void k_fast_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, FrameGeom g,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, FrameGeom g,
                                                   FastLds fl, SlideMap sm, uint32_t* __restrict__ cell_cand,
                                                   int* __restrict__ cell_count, const FastCell* __restrict__ cells,
                                                   int frame_per_xcd, unsigned long long rcp_nitems, int nitems, int nframes)

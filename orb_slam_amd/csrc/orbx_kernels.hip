@@ -670,13 +670,8 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
             const us2_t mO = compass2(odd_bytes(av), odd_bytes(a0), odd_bytes(a8), odd_bytes(a4), odd_bytes(a12));
             // invalid pixels (columns past the cell, rows past it in the last round) get the threshold 0xffff:
             // their saturated difference is 0
-            // only the last round can hold rows past the cell (wave-uniform test: the other rounds skip the selects)
-            uint32_t tEw = thrE, tOw = thrO;
-            if (y0 + R > ch) {
-                const bool row_ok = row < ch;
-                tEw = row_ok ? thrE : 0xffffffffu;
-                tOw = row_ok ? thrO : 0xffffffffu;
-            }
+            const bool row_ok = row < ch;
+            const uint32_t tEw = row_ok ? thrE : 0xffffffffu, tOw = row_ok ? thrO : 0xffffffffu;
             const us2_t tE = __builtin_bit_cast(us2_t, tEw), tO = __builtin_bit_cast(us2_t, tOw);
             const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, tE));
             const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, tO));

@@ -79,7 +79,7 @@ struct orbx_ctx {
 
     // per-batch working set
     int cap_frames = 0;
-    DevBuf pyr, blur, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand;
+    DevBuf pyr, blur, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, qt_scratch;
 
     // staging for the host-buffer entry points
     DevBuf in, out_kps, out_desc, out_n;
@@ -206,6 +206,7 @@ int ensure_frames(orbx_ctx* c, int nframes)
     HIPCHECK(c, c->kp_stage.ensure((n * (size_t)g.kp_per_frame + 64) * 8));
     HIPCHECK(c, c->level_count.ensure(n * kMaxLevels * 4));
     HIPCHECK(c, c->level_ncand.ensure(n * kMaxLevels * 4));
+    HIPCHECK(c, c->qt_scratch.ensure(n * kMaxLevels * quadtree_scratch_stride(g)));   // only for levels beyond 2048 nodes
     // the blurred planes are only written inside the level images; give the rest a defined value once
     HIPCHECK(c, hipMemsetAsync(c->blur.p, 0, c->blur.bytes, c->stream));
     c->cap_frames = nframes;
@@ -296,7 +297,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);
     launch_quadtree(g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand,
-                    nframes, s);
+                    nframes, c->qt_scratch.as<unsigned char>() + F * kMaxLevels * quadtree_scratch_stride(g), s);
     t1(ST_QUADTREE, s);
     if (overlap) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     t0(ST_DESC, s);
@@ -504,7 +505,7 @@ void orbx_destroy(orbx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)finish(c);
     DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
-                      &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->in, &c->out_kps,
+                      &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->qt_scratch, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],

@@ -13,6 +13,7 @@ constexpr int kDetBorder = 16;         // minBorderX/Y = EDGE_THRESHOLD-3, src/O
 constexpr int kPadX = 32;              // left/right padding of a pyramid plane row (>= kEdge, keeps rows dword-friendly)
 constexpr int kPadY = kEdge;           // top/bottom padding of a pyramid plane
 constexpr int kMaxNodes = 2048;        // quadtree nodes one workgroup can hold in LDS
+constexpr int kMaxNodesBig = 16384;    // ... and in its slice of global memory (14-bit node index)
 constexpr int kPatchPixels = 749;      // pixels of the circular orientation patch
 
 // One pyramid level of one frame geometry (identical for every frame of a batch).

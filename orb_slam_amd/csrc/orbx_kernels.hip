@@ -1033,15 +1033,21 @@ __device__ __forceinline__ int ceil_half(int d)
     return (d + 1) >> 1;
 }
 
-template <int NT, int KR>
+// NB = bits of a node index in a key's node word (node | quadrant << NB, 16 bits in all).  NB = 11: the node
+// arrays of up to 2048 nodes live in LDS.  NB = 14: levels asked for more features than that keep the same arrays
+// in a per-workgroup slice of global memory (gscratch): far slower, but the result is the same and no setting is refused
+// up to 16376 features on one level.
+template <int NT, int KR, int NB>
 __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
                                                   uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
                                                   int* __restrict__ level_count, int* __restrict__ level_ncand,
-                                                  int off_in_lds)
+                                                  int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride)
 {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char smem_lds[];
+    unsigned char* const smem = NB > 11 ? gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * gstride : smem_lds;
+    constexpr uint32_t kNodeMask = (1u << NB) - 1u;
     const int level = blockIdx.y, f = blockIdx.x;   // x = frame: the large low levels are dispatched first
     const LevelGeom& L = g.lv[level];
     const int tid = threadIdx.x;
@@ -1101,7 +1107,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     // The first KR*NT keys live in registers (coordinates, response and current node);
     // only the rare overflow beyond that walks the global arrays.  FOR_KEYS(body) runs body
     // for every key of this thread with `i` (key index), `xy` (packed coordinates) and `nd`
-    // (node word: node | quadrant << 11 | response << 16, written back afterwards).
+    // (node word: node | quadrant << NB | response << 16, written back afterwards).
     uint32_t rxy[KR], rnode[KR];
     auto fetch_key = [&](int i, uint32_t& xy, uint32_t& resp) {
         int lo = 0, hi = ncell;                 // largest c with off[c] <= i
@@ -1205,7 +1211,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
     __syncthreads();
 
-    const bool packed_rank = n < (1 << 19);
+    const bool packed_rank = NB == 11 && n < (1 << 19);   // the packed key holds creation indices below 4 * 2048
     // ---- splitting steps
     while (true) {
         size = s_var[4];
@@ -1231,14 +1237,14 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
         // c. child occupancy (DivideNode :431-476)
         FOR_KEYS({
-            int p = (int)(nd & 0x7ff);
+            int p = (int)(nd & kNodeMask);
             if (s_fl[p]) {
                 QNode q = rc[p];
                 int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
                 int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
                 int qd = (x < q.x0 + hx ? 0 : 1) + (y < q.y0 + hy ? 0 : 2);
                 atomicAdd(&s_cc[4 * p + qd], 1);
-                nd = (uint32_t)(p | (qd << 11));
+                nd = (uint32_t)(p | (qd << NB));
             }
         })
         if (!phase2) {
@@ -1347,8 +1353,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         __syncthreads();
         // f. move the keys
         FOR_KEYS({
-            int p = (int)(nd & 0x7ff);
-            nd = s_fl[p] ? s_childpos[4 * p + (int)(nd >> 11)] : s_newpos[p];
+            int p = (int)(nd & kNodeMask);
+            nd = s_fl[p] ? s_childpos[4 * p + (int)(nd >> NB)] : s_newpos[p];
         })
         // g. loop control (:618-622, :683-684)
         if (tid == 0) {
@@ -1367,7 +1373,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     __syncthreads();
     FOR_KEYS({
         unsigned long long v = ((unsigned long long)resp << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-        atomicMax(&s_best[nd & 0x7ff], v);
+        atomicMax(&s_best[nd & kNodeMask], v);
     })
 #undef FOR_KEYS
     __syncthreads();
@@ -1382,15 +1388,17 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 #define QUADTREE_PARAMS FrameGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_count,          \
                         int* __restrict__ cell_off, uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,      \
                         uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage, int* __restrict__ level_count,   \
-                        int* __restrict__ level_ncand, int off_in_lds
-#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds
+                        int* __restrict__ level_ncand, int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride
+#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds, gscratch, gstride
 // Two shapes of the same body.  256 threads x 10 register keys (91 VGPRs, 5 wavefronts per SIMD) is
 // the throughput shape for batches.  1024 threads x 3 register keys shortens the per-key passes of
 // a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
-__global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs>(QUADTREE_ARGS); }
-__global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs, 11>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 11>(QUADTREE_ARGS); }
 // 512 threads x 5 register keys: between the two, for batches that fill the device only once
-__global__ __launch_bounds__(512) void k_quadtree_mid(QUADTREE_PARAMS) { quadtree_body<512, 5>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(512) void k_quadtree_mid(QUADTREE_PARAMS) { quadtree_body<512, 5, 11>(QUADTREE_ARGS); }
+// more than 2048 nodes on a level: node arrays in global memory
+__global__ __launch_bounds__(1024) void k_quadtree_big(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 14>(QUADTREE_ARGS); }
 #undef QUADTREE_ARGS
 #undef QUADTREE_PARAMS
 
@@ -1755,12 +1763,25 @@ static size_t quadtree_total_lds(const FrameGeom& g, int* off_in_lds)
     return *off_in_lds ? fixed + offs : fixed;
 }
 
+// bytes of global scratch one (frame, level) workgroup of k_quadtree_big uses; 0 when the LDS shapes serve the geometry
+size_t quadtree_scratch_stride(const FrameGeom& g)
+{
+    if (g.max_nodes <= kMaxNodes) return 0;
+    return (quadtree_fixed_lds(g.max_nodes) + ((size_t)max_level_cells(g) + 1) * 4 + 255) & ~(size_t)255;
+}
+
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
-                     int* level_ncand, int nframes, hipStream_t s)
+                     int* level_ncand, int nframes, unsigned char* gscratch, hipStream_t s)
 {
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
+    if (g.max_nodes > kMaxNodes) {      // node arrays (and the cell offsets behind them) in global memory
+        hipLaunchKernelGGL(k_quadtree_big, grid, dim3(1024), 0, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, 1, gscratch,
+                           quadtree_scratch_stride(g));
+        return;
+    }
     size_t lds = quadtree_total_lds(g, &off_in_lds);
     // up to one workgroup per CU (32 frames x 8 levels) the wide shape is fastest, up to about 112 frames the
     // 512-thread one, beyond that the narrow one (measured: 0.040 against 0.052 ms at 64 frames, 0.106 against 0.061 at 256)
@@ -1770,17 +1791,18 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     const int wide_max = e_wide ? atoi(e_wide) : 32, mid_max = e_mid ? atoi(e_mid) : 112;
     if (nframes <= wide_max)
         hipLaunchKernelGGL(k_quadtree_wide, grid, dim3(1024), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
     else if (nframes <= mid_max)
         hipLaunchKernelGGL(k_quadtree_mid, grid, dim3(512), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
     else
         hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
 }
 
 int quadtree_prepare(int max_nodes)
 {
+    if (max_nodes > kMaxNodes) return 0;     // k_quadtree_big keeps its arrays in global memory
     size_t lds = quadtree_lds_bytes(max_nodes);
     if (lds > 160 * 1024) return -1;
     if (lds > 64 * 1024) {

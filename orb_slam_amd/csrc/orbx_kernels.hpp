@@ -46,7 +46,8 @@ size_t quadtree_lds_bytes(int max_nodes);
 int quadtree_prepare(int max_nodes);
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
-                     int* level_ncand, int nframes, hipStream_t s);
+                     int* level_ncand, int nframes, unsigned char* gscratch, hipStream_t s);
+size_t quadtree_scratch_stride(const FrameGeom& g);
 void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
                         const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
                         int nframes, hipStream_t s);

@@ -170,7 +170,7 @@ int build_geometry(const Params& p, int w, int h, FrameGeom& g, ResizeTables& ta
             if (L.nIni < 1) { *msg = "image taller than twice its width (the reference divides by zero)"; return ORBX_ERR_UNSUPPORTED; }
             L.hX = (float)width / L.nIni;
             L.kp_cap = std::max(L.nfeat + 3, 4 * L.nIni);
-            if (L.kp_cap + 4 > kMaxNodes) { *msg = "more than 2040 features on one level"; return ORBX_ERR_UNSUPPORTED; }
+            if (L.kp_cap + 4 > kMaxNodesBig) { *msg = "more than 16376 features on one level"; return ORBX_ERR_UNSUPPORTED; }
             max_nodes = std::max(max_nodes, L.kp_cap + 4);
             kps += (L.kp_cap + 7) & ~7;    // whole groups of 8 slots per level: a descriptor workgroup (8 keypoints) never straddles levels
         }

@@ -395,6 +395,32 @@ def test_cpp_adapter_program(euroc_left, tmp_path):
     assert "adapter ok: 1009 keypoints, 8 levels" in p.stdout.decode()
 
 
+@pytest.mark.parametrize("nfeat,size,seed", [(12000, (720, 1280), 5), (30000, (1080, 1920), 6)])
+def test_more_than_2048_nodes_per_level(nfeat, size, seed):
+    """Levels that are asked for more than 2040 features (nFeatures above about 9400) do not fit the
+    quadtree's LDS arrays; they run with the arrays in global memory and must give the same keypoints."""
+    from orb_slam_amd import ORBextractor
+    h, w = size
+    rng = np.random.default_rng(seed)
+    img = synthetic_frame(w, h, 300 + seed, nrect=1200)
+    img[: h // 2] = rng.integers(0, 256, size=(h // 2, w), dtype=np.uint8)      # noise half: plenty of candidates
+    ex = ORBextractor(nfeat, 1.2, 8, 20, 7)
+    orc = Oracle(nfeat, 1.2, 8, 20, 7)
+    assert ex.GetFeaturesPerLevel()[0] > 2040
+    kps_g, desc_g = ex(img)
+    kps_o, desc_o = orc.extract(img, literal=True, cap=nfeat + 1000)
+    assert len(kps_o) > 0.9 * nfeat
+    assert np.array_equal(ex.debug_level_counts(), orc.last_level_counts())
+    _assert_features(kps_g, desc_g, kps_o, desc_o)
+    assert np.array_equal(desc_g, desc_o)
+    # a batch of two through the same path
+    res = ex.extract_batch(np.stack([img, img[::-1].copy()]))
+    assert np.array_equal(res[0][0], kps_g) and np.array_equal(res[0][1], desc_g)
+    k2, d2 = orc.extract(img[::-1].copy(), literal=True, cap=nfeat + 1000)
+    _assert_features(res[1][0], res[1][1], k2, d2)
+    ex.close()
+
+
 def test_4k_8000_features():
     """3840x2160, 8000 features: 1737-node quadtree (LDS above 64 KB), > 4096 candidates per
     level (keys beyond the register-resident ones), 8820 cells on level 0."""

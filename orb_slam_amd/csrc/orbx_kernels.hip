@@ -542,7 +542,27 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     // Tile load: 16 lanes per tile row (32 when the pitch is not the compiled-in one), whole rows per
     // step, so that every address is the previous one plus a constant.  A denser packing of the
     // lanes needs fewer loads but a division per dword, and this kernel is bound by instruction issue.
-    {
+    if (TPC && th <= 48) {
+        // Compiled-in pitch: unrolled steps of 4 rows.  Buffer loads take the lane's constant 32-bit offset plus a
+        // scalar row offset, the stores a constant LDS offset: no vector arithmetic per step, and every load is in
+        // flight before the first store.  The buffer ends with the frame's pyramid, so that no address can fault.
+        // The last step may write up to 3 rows past the tile's rows: unused tile rows or the head of the score
+        // tile, which is cleared right after.
+        const int rr = lane >> 4, cc = lane & 15;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(src), 0, (int)(g.pyr_frame_bytes - (size_t)fc.src_off), 0x00020000);
+        if (cc < ndw) {
+            const int so = __mul24(rr, pitch) + 4 * cc;
+            uint32_t* d = s_tile + rr * (TPC >> 2) + cc;
+            uint32_t v[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (4 * k < th) v[k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rsrc, so, 4 * k * pitch, 0);
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                if (4 * k < th) d[k * 4 * (TPC >> 2)] = v[k];
+        }
+    } else {
         constexpr int LPR = TPC ? 16 : 32, RPS = 64 / LPR;
         const int rr = lane / LPR, cc = lane & (LPR - 1);
         if (cc < ndw) {

@@ -1,16 +1,20 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence of one round on the GPU box.  Usage (from the repo root):
 #   bash tools/profile_round.sh <tag>
-# Writes gpurun_out/prof_<tag>/{stats,pmc_fetch,pmc_write,pmc_sq1,pmc_sq2,pmc_tcp}/... and the per-launch summaries; tools/make_traffic.py turns the
-# counter files into profiles/traffic.json.  Each profiler pass is its own short run.
+# Writes gpurun_out/prof_<tag>/... : kernel trace + stats of the default bench command and of the headline
+# workload alone, the counter passes (each its own short run) and their per-launch summaries;
+# tools/make_traffic.py / tools/make_issue.py turn the counter files into profiles/traffic.json / issue.json.
 set -e -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export PYTHONPATH=$ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -s KILL 280 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+# the default command (headline workload + legs of the other configs + CPU baseline)
+timeout -s KILL 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $ROOT/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+# the headline workload alone: per-kernel averages that are not mixed with the other configs' launches
+timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_headline -o bench -- python3 $ROOT/bench.py --no-extras --no-cpu-baseline > $OUT/bench_headline_under_rocprof.json 2> $OUT/bench_headline_under_rocprof.err
 timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o pmc -- python3 $ROOT/tools/stage_bench.py 256 2 > $OUT/pmc_write.log 2>&1
 # issue / wait counters: at most 8 SQ and 4 TCP counters per pass
@@ -20,4 +24,7 @@ timeout -s KILL 120 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_RE
 cd $ROOT
 python3 tools/pmc_summary.py $(find $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_tcp -name '*counter_collection.csv') > $OUT/pmc_sq_tcp_per_launch.txt
 python3 tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name '*counter_collection.csv') > $OUT/pmc_fetch_write_per_launch.txt
-ls -R $OUT | head -60
+python3 tools/make_traffic.py $(find $OUT/pmc_fetch -name '*counter_collection.csv') $(find $OUT/pmc_write -name '*counter_collection.csv') $OUT/traffic.json > /dev/null
+python3 tools/make_issue.py $(find $OUT/pmc_sq1 -name '*counter_collection.csv') $OUT/issue.json > /dev/null
+python3 tools/trace_filter.py $(find $OUT/stats -name '*kernel_trace.csv') k_fast_blur > $OUT/fast_blur_headline_shape_in_default_run.txt
+ls -R $OUT | head -80

@@ -675,10 +675,10 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         const uint32_t thrE = r < R ? (t32 | ~colE) : 0xffffffffu, thrO = r < R ? (t32 | ~colO) : 0xffffffffu;
         const uint32_t one2 = 0x00010001u;
         const int step_w = __mul24(R, TPW);
-        for (int y0 = 0; y0 < ch; y0 += R) {
-            if (nq + 256 > qcap) { score_queue(); nq = 0; flushed = true; }
+        // one group of four pixels per lane: counts (1 per survivor) and queue entries of its even / odd pixels
+        auto group = [&](int w, int rw, uint32_t iE, uint32_t iO, us2_t& cE, us2_t& cO, us2_t& eE, us2_t& eO) {
             // rows past the cell still lie inside the LDS block (the score tile follows): read, then discard
-            const uint32_t* qa = s_tile + w0;
+            const uint32_t* qa = s_tile + w;
             const uint32_t* qv = qa + (jv >> 2);
             const uint32_t* q4 = qa + (j4 >> 2);
             const uint32_t a8 = __builtin_amdgcn_alignbyte(qv[1], qv[0], jv & 3);
@@ -688,23 +688,18 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
             const uint32_t a4 = __builtin_amdgcn_alignbyte(q4[TPW3 + 1], q4[TPW3], j4 & 3);
             const us2_t mE = compass2(even_bytes(av), even_bytes(a0), even_bytes(a8), even_bytes(a4), even_bytes(a12));
             const us2_t mO = compass2(odd_bytes(av), odd_bytes(a0), odd_bytes(a8), odd_bytes(a4), odd_bytes(a12));
-            // invalid pixels (columns past the cell, rows past it in the last round) get the threshold 0xffff:
-            // their saturated difference is 0
-            const bool row_ok = row < ch;
+            // invalid pixels (columns past the cell, rows past it) get the threshold 0xffff: their saturated difference is 0
+            const bool row_ok = rw < ch;
             const uint32_t tEw = row_ok ? thrE : 0xffffffffu, tOw = row_ok ? thrO : 0xffffffffu;
             const us2_t tE = __builtin_bit_cast(us2_t, tEw), tO = __builtin_bit_cast(us2_t, tOw);
-            const uint32_t dE = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mE, tE));
-            const uint32_t dO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(mO, tO));
-            const us2_t cE = pk_min_u16(__builtin_bit_cast(us2_t, dE), one2);          // 1 per survivor
-            const us2_t cO = pk_min_u16(__builtin_bit_cast(us2_t, dO), one2);
+            cE = pk_min_u16(__builtin_elementwise_sub_sat(mE, tE), one2);          // 1 per survivor
+            cO = pk_min_u16(__builtin_elementwise_sub_sat(mO, tO), one2);
             // entry = index | 0x8000 if the pretest value exceeds iniThFAST: m + (0x7fff - ts) carries into bit 15
             // exactly then (m <= 255), and the index stays below 0x1000
-            const us2_t eE = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mE + ts2) & 0x80008000u) | idxE);
-            const us2_t eO = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mO + ts2) & 0x80008000u) | idxO);
-            const uint32_t both = __builtin_bit_cast(uint32_t, cE) + __builtin_bit_cast(uint32_t, cO);
-            const int cnt = (int)((both & 0xffffu) + (both >> 16));
-            const int incl = wave_incl_scan(cnt);
-            int pos = nq + incl - cnt;
+            eE = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mE + ts2) & 0x80008000u) | iE);
+            eO = __builtin_bit_cast(us2_t, (__builtin_bit_cast(uint32_t, mO + ts2) & 0x80008000u) | iO);
+        };
+        auto put = [&](int pos, us2_t cE, us2_t cO, us2_t eE, us2_t eO) {
             if (cE.x) s_queue[pos] = eE.x;
             pos += cE.x;
             if (cO.x) s_queue[pos] = eO.x;
@@ -712,11 +707,38 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
             if (cE.y) s_queue[pos] = eE.y;
             pos += cE.y;
             if (cO.y) s_queue[pos] = eO.y;
-            nq += __builtin_amdgcn_readlane(incl, 63);
-            w0 += step_w;
-            row += R;
-            idxE += step2;
-            idxO += step2;
+        };
+        // Two rounds of R rows per iteration (rows y0 .. y0 + R - 1, then the next R): their counts share one
+        // wave scan, packed as two 16-bit fields; all entries of the first round precede those of the second.
+        // The queue holds qcap >= 512 entries, enough for any natural image.  When a pair of rounds does not fit
+        // (noise: most pixels pass), the loop is left, the queued pixels are scored at once, the queue restarts and
+        // the loop resumes with the same pair (leaving the loop keeps the rare path out of its register budget).
+        int y0 = 0;
+        while (true) {
+            bool full = false;
+            for (; y0 < ch; y0 += 2 * R) {
+                us2_t cEa, cOa, eEa, eOa, cEb, cOb, eEb, eOb;
+                group(w0, row, idxE, idxO, cEa, cOa, eEa, eOa);
+                group(w0 + step_w, row + R, idxE + step2, idxO + step2, cEb, cOb, eEb, eOb);
+                const uint32_t ba = __builtin_bit_cast(uint32_t, cEa) + __builtin_bit_cast(uint32_t, cOa);
+                const uint32_t bb = __builtin_bit_cast(uint32_t, cEb) + __builtin_bit_cast(uint32_t, cOb);
+                const int cnta = (int)((ba & 0xffffu) + (ba >> 16)), cntb = (int)((bb & 0xffffu) + (bb >> 16));
+                const int incl = wave_incl_scan(cnta | (cntb << 16));
+                const int tot = __builtin_amdgcn_readlane(incl, 63);
+                const int tota = tot & 0xffff, totb = tot >> 16;
+                if (nq + tota + totb > qcap) { full = true; break; }
+                put(nq + (incl & 0xffff) - cnta, cEa, cOa, eEa, eOa);
+                put(nq + tota + (incl >> 16) - cntb, cEb, cOb, eEb, eOb);
+                nq += tota + totb;
+                w0 += 2 * step_w;
+                row += 2 * R;
+                idxE += 2 * step2;
+                idxO += 2 * step2;
+            }
+            if (!full) break;
+            score_queue();
+            nq = 0;
+            flushed = true;
         }
     }
     uint32_t* out = cell_cand + (size_t)f * g.cand_per_frame + fc.cand_off;
@@ -1438,8 +1460,8 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
     fl.queue_off = (fl.score_off + score_bytes + 15) & ~15;
     // a queue for 640 pretest survivors (natural images: about 200 of a cell's ~1000 pixels) instead of one
     // for every pixel keeps a wavefront's LDS under 5 KB, i.e. 8 wavefronts per SIMD
-    // (never below 256: one pretest round can queue four pixels per lane)
-    fl.queue_cap = std::max(256, std::min((wc * hc + 63) & ~63, getenv("ORBX_FAST_QCAP") ? atoi(getenv("ORBX_FAST_QCAP")) : 640));
+    // (never below 512: a pair of pretest rounds can queue eight pixels per lane)
+    fl.queue_cap = std::max(512, std::min((wc * hc + 63) & ~63, getenv("ORBX_FAST_QCAP") ? atoi(getenv("ORBX_FAST_QCAP")) : 640));
     fl.total = fl.queue_off + 2 * fl.queue_cap + 16;
     fl.total = (fl.total + 15) & ~15;
 }

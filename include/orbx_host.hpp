@@ -7,6 +7,7 @@
 // a GPU call can, so failures surface as std::runtime_error with the text of
 // orbx_last_error().
 #pragma once
+#include <algorithm>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -130,6 +131,90 @@ inline void UndistortKeyPoints(ORBextractor& ex, const std::vector<orbx_keypoint
                                       p_cols, fisheye ? 1 : 0, keysUn.data());
     if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ex.context()));
 }
+
+// The delayed stereo matching of the reference's default build (DELAYED_STEREO_MATCHING, include/Frame.h:38-40):
+// the Frame members PrepareStereoCandidates sets up (include/Frame.h:217-251) and the calls that fill them in
+// several steps (src/Frame.cc:1175-1260, :1262-1422), with the searches on the device through
+// orbx_stereo_match_ex.  A Frame keeps one of these next to mvKeysUn / mvKeysRightUn / mDescriptors /
+// mDescriptorsRight and replaces the bodies of the three member functions by the calls below.
+//   has_mappoint[iL] = (mvpMapPoints[iL] != NULL)
+//   prior_disp[iL]   = mbf / Pc.z of a map point that is not bad and lies in front of the camera (:1325-1334), else <= 0
+struct DelayedStereo {
+    static constexpr float kDisparityThres = 50.0f;   // DISPARITY_THRES, include/Frame.h:47
+
+    std::vector<float> mvuRight, mvDepth;
+    std::vector<uint8_t> mvStereoMatched, has_mappoint;
+    std::vector<float> prior_disp;
+    std::vector<int32_t> listed_dist;     // mvDistIdx, indexed by left keypoint (-1: not listed)
+    std::vector<int32_t> best_idx, best_dist;
+
+    // Frame::PrepareStereoCandidates (the row table itself is implicit in the device search)
+    void PrepareStereoCandidates(int N)
+    {
+        mvuRight.assign(N, -1.0f);
+        mvDepth.assign(N, -1.0f);
+        mvStereoMatched.assign(N, 0);
+        has_mappoint.resize(N, 0);
+        prior_disp.resize(N, 0.0f);
+        listed_dist.assign(N, -1);
+        best_idx.assign(N, -1);
+        best_dist.assign(N, 100);
+    }
+
+    // Frame::ComputeStereoMatches_Undistorted(isOnline); returns nmatched
+    int ComputeStereoMatches_Undistorted(ORBextractor& ex, bool isOnline, const std::vector<orbx_keypoint>& keysUn,
+                                         const uint8_t* desc, const std::vector<orbx_keypoint>& keysRightUn,
+                                         const uint8_t* descRight, int nRows, float mbf, float mb, float mnMinX)
+    {
+        const int N = (int)keysUn.size();
+        if (N == 0) return 0;
+        std::vector<uint8_t> active(N);
+        std::vector<float> minD(N, 0.0f), maxD(N, mbf / mb);
+        for (int i = 0; i < N; i++) {
+            active[i] = isOnline ? (has_mappoint[i] && !mvStereoMatched[i]) : !mvStereoMatched[i];   // :1283-1297
+            if (has_mappoint[i] && prior_disp[i] > 0) {                                              // :1325-1338
+                minD[i] = std::max(prior_disp[i] - kDisparityThres, 0.0f);
+                maxD[i] = std::min(prior_disp[i] + kDisparityThres, mbf / mb);
+            }
+            if (active[i]) mvStereoMatched[i] = 1;                                                   // :1304
+        }
+        int nmatched = 0;
+        check(ex, orbx_stereo_match_ex(ex.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc), N,
+                                       keysRightUn.data(), reinterpret_cast<const uint32_t*>(descRight),
+                                       (int)keysRightUn.size(), nRows, mbf, mb, mnMinX, active.data(), minD.data(),
+                                       maxD.data(), 75, isOnline ? 0 : 1, listed_dist.data(), best_idx.data(),
+                                       best_dist.data(), mvuRight.data(), mvDepth.data(), &nmatched));
+        return nmatched;
+    }
+
+    // Frame::ComputeStereoMatch_OnePoint(iL, thOrbDist, minD, maxD)
+    bool ComputeStereoMatch_OnePoint(ORBextractor& ex, int iL, int thOrbDist, float minD, float maxD,
+                                     const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc,
+                                     const std::vector<orbx_keypoint>& keysRightUn, const uint8_t* descRight, int nRows,
+                                     float mbf, float mb)
+    {
+        const int N = (int)keysUn.size();
+        if (iL < 0 || iL >= N) return false;
+        if (!has_mappoint[iL] || mvStereoMatched[iL]) return false;
+        mvStereoMatched[iL] = 1;
+        std::vector<uint8_t> active(N, 0);
+        active[iL] = 1;
+        std::vector<float> mn(N, minD), mx(N, maxD);
+        int nmatched = 0;
+        check(ex, orbx_stereo_match_ex(ex.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc), N,
+                                       keysRightUn.data(), reinterpret_cast<const uint32_t*>(descRight),
+                                       (int)keysRightUn.size(), nRows, mbf, mb, 0.0f, active.data(), mn.data(), mx.data(),
+                                       thOrbDist, 0, listed_dist.data(), best_idx.data(), best_dist.data(),
+                                       mvuRight.data(), mvDepth.data(), &nmatched));
+        return listed_dist[iL] >= 0;
+    }
+
+private:
+    static void check(ORBextractor& ex, int rc)
+    {
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ex.context()));
+    }
+};
 
 // ORBmatcher::DescriptorDistance (include/ORBmatcher.h:48) on raw 32-byte rows
 inline int DescriptorDistance(const uint8_t* a, const uint8_t* b)

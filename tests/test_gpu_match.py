@@ -393,3 +393,58 @@ def test_stereo_ex_device_batched(ex, matcher, oracle):
         assert np.array_equal(listed[b, :n], o.listed_dist()[:n]), b
         assert np.array_equal(ur[b, :n], o.mvuRight[:n]) and np.array_equal(dp[b, :n], o.mvDepth[:n]), b
         assert (listed[b, n:] == -1).all() and (ur[b, n:] == -1).all()
+
+
+def test_cpp_delayed_stereo_class(ex, oracle, tmp_path):
+    """orbx::DelayedStereo (include/orbx_host.hpp), the C++ form a Frame of the reference would hold, through
+    the same online / one-point / offline sequence as the oracle's Frame state."""
+    import os
+    import struct
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "stereo_delayed")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "stereo_delayed"])
+    rng = np.random.default_rng(12)
+    n = 1500
+    kl, dl, kr, dr = _random_stereo_sets(rng, n)
+    kr, dr = kr[:1300], dr[:1300]
+    sf = ex.GetScaleFactors()
+    mbf, mb, min_x = 47.9, 0.11, 2.0
+    has_mp = (rng.random(n) < 0.4).astype(np.uint8)
+    prior = np.where(rng.random(n) < 0.75, rng.uniform(0.5, 120, n), -1.0).astype(np.float32)
+    pts = []
+    fresh = np.flatnonzero(has_mp == 0)[:10]
+    for j, iL in enumerate(list(fresh) + [int(np.flatnonzero(has_mp)[0]), -1, n]):
+        pts.append((int(iL), (75, 60, 100)[j % 3], float(np.float32(rng.uniform(0, 20))), float(np.float32(rng.uniform(30, 400))), 1))
+    o = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, mbf, mb, min_x)
+    o.has_mappoint[:n] = has_mp
+    o.prior_disp[:n] = prior
+    nm_on = o.ComputeStereoMatches_Undistorted(True)
+    res = []
+    for iL, th, mn, mx, add in pts:
+        if 0 <= iL < n:
+            o.has_mappoint[iL] = 1
+        res.append(o.ComputeStereoMatch_OnePoint(iL, th, mn, mx))
+    nm_off = o.ComputeStereoMatches_Undistorted(False)
+    inp, outp = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(inp, "wb") as f:
+        f.write(struct.pack("<4i3f", n, len(kr), 480, len(pts), mbf, mb, min_x))
+        f.write(kl.tobytes()); f.write(dl.tobytes()); f.write(kr.tobytes()); f.write(dr.tobytes())
+        f.write(has_mp.tobytes()); f.write(prior.tobytes())
+        for iL, th, mn, mx, add in pts:
+            f.write(struct.pack("<2i2fB", iL, th, mn, mx, add))
+    subprocess.check_call([exe, str(inp), str(outp)], timeout=100)
+    buf = outp.read_bytes()
+    g_on, g_off = struct.unpack_from("<2i", buf, 0)
+    off = 8
+    g_res = np.frombuffer(buf, np.uint8, len(pts), off); off += len(pts)
+    g_ur = np.frombuffer(buf, np.float32, n, off); off += 4 * n
+    g_dp = np.frombuffer(buf, np.float32, n, off); off += 4 * n
+    g_listed = np.frombuffer(buf, np.int32, n, off); off += 4 * n
+    g_matched = np.frombuffer(buf, np.uint8, n, off)
+    assert (g_on, g_off) == (nm_on, nm_off)
+    assert list(g_res != 0) == res
+    assert np.array_equal(g_ur, o.mvuRight[:n]) and np.array_equal(g_dp, o.mvDepth[:n])
+    assert np.array_equal(g_listed, o.listed_dist()[:n])
+    assert np.array_equal(g_matched != 0, o.mvStereoMatched[:n] != 0)

@@ -85,7 +85,7 @@ struct orbx_ctx {
     DevBuf in, out_kps, out_desc, out_n;
     // scratch for matching
     DevBuf partial, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
-    DevBuf grid_start, grid_list, gq[12], stereo_listed;
+    DevBuf grid_start, grid_list, gq[12], stereo_listed, stereo_rows;
 
     int last_nframes = 0;
     bool have_pyramid = false, have_features = false;
@@ -509,7 +509,7 @@ void orbx_destroy(orbx_ctx* c)
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],
-                      &c->stereo_listed};
+                      &c->stereo_listed, &c->stereo_rows};
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
@@ -1053,8 +1053,17 @@ static int stereo_launch(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t*
     if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
     if (th_orb_dist < 0 || th_orb_dist > 256) return fail(c, ORBX_ERR_INVALID, "th_orb_dist must be in [0, 256]");
     if (median_cut && !d_listed) return fail(c, ORBX_ERR_INVALID, "the median cut needs the listed-distance array");
+    if (nrows > 16000) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 16000 image rows");
     HIPCHECK(c, hipSetDevice(c->device));
+    {   // scratch for the row ordering of the right keypoints
+        const size_t need = stereo_rows_ints(nbatch, stride, nrows) * 4;
+        if (need > c->stereo_rows.bytes) {
+            HIPCHECK(c, finish(c));
+            HIPCHECK(c, c->stereo_rows.ensure(need));
+        }
+    }
     StereoLaunch L;
+    L.d_rows = c->stereo_rows.as<int32_t>();
     L.d_kl = d_kl; L.d_kr = d_kr; L.d_dl = d_dl; L.d_dr = d_dr; L.d_nl = d_nl; L.d_nr = d_nr;
     L.d_active = d_active; L.d_min_d = d_min_d; L.d_max_d = d_max_d; L.d_listed = d_listed;
     L.d_best_idx = d_best_idx; L.d_best_dist = d_best_dist; L.d_u_right = d_u_right; L.d_depth = d_depth;
@@ -1216,9 +1225,16 @@ int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* 
         HIPCHECK(c, hipEventRecord(c->ev_pyr, r->stream));
         HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_pyr, 0));
     }
+    {
+        const size_t need = stereo_rows_ints(nbatch, stride, c->g.lv[0].h) * 4;
+        if (need > c->stereo_rows.bytes) {
+            HIPCHECK(c, finish(c));
+            HIPCHECK(c, c->stereo_rows.ensure(need));
+        }
+    }
     launch_stereo_classic(d_kl, d_dl, d_nl, d_kr, d_dr, d_nr, nbatch, stride, c->pyr.as<uint8_t>(), r->pyr.as<uint8_t>(),
                           c->g, c->p.scale, c->p.inv_scale, mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth,
-                          d_nmatched, c->stream);
+                          d_nmatched, c->stereo_rows.as<int32_t>(), c->stream);
     HIPCHECK(c, hipGetLastError());
     return ORBX_OK;
 }

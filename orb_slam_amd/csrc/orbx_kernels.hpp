@@ -74,6 +74,7 @@ struct StereoLaunch {
     const uint8_t* d_active;
     const float *d_min_d, *d_max_d;
     int32_t* d_listed;
+    int32_t* d_rows;               // stereo_rows_ints(nbatch, stride, nrows) ints of scratch for the row ordering
     int32_t *d_best_idx, *d_best_dist;
     float *d_u_right, *d_depth;
     int32_t* d_nmatched;
@@ -81,13 +82,14 @@ struct StereoLaunch {
     float mbf, mb, min_x;
 };
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s);
+size_t stereo_rows_ints(int nbatch, int stride, int nrows);
 
 void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
                            const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,
                            int nbatch, int stride, const uint8_t* pyrL, const uint8_t* pyrR, const FrameGeom& g,
                            const float* scale8, const float* inv_scale8, float mbf, float mb,
                            int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
-                           int32_t* d_nmatched, hipStream_t s);
+                           int32_t* d_nmatched, int32_t* d_rows, hipStream_t s);
 
 constexpr int kFrameGridCells = 64 * 48;   // FRAME_GRID_COLS x FRAME_GRID_ROWS, include/Frame.h:92-93
 // camera model of Frame::UndistortKeyPoints: K, distortion coefficients, RR = P(:, 0:3) * R

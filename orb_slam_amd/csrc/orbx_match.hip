@@ -422,10 +422,11 @@ uint32_t* match_static_scratch(int device, hipError_t* err)
 // A right keypoint is a candidate of left keypoint iL iff int(vL) lies in its row band
 // [max(0, floor(y-r)), min(nRows-1, ceil(y+r))], r = 2*scaleFactor[octave]; the reference visits a
 // row's candidates in ascending iR and keeps the first minimum below TH_HIGH, i.e. the minimum of
-// (distance, iR), so no row table is materialised: one wavefront per left keypoint, its lanes
+// (distance, iR), so the visiting order is free: one wavefront per left keypoint, its lanes
 // stride over the right keypoints, test band / octave / disparity window, and the wave minimum of
-// distance << 22 | iR is taken with DPP moves.  Work of a pair spreads over the whole device and
-// there is no limit on the number of keypoints.
+// distance << 22 | iR is taken with DPP moves.  The lanes only visit the right keypoints of the rows around
+// the left keypoint's (k_stereo_rows orders them by row first).  Work of a pair spreads over the whole
+// device and there is no limit on the number of keypoints.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
@@ -451,16 +452,72 @@ struct StereoArgs {
     int32_t* nmatched;
     int stride, nrows, th_orb_dist;
     float mbf, mb, min_x;
+    const int32_t* row_start;       // per pair nrows + 1 offsets into sorted: right keypoints ordered by clamp(floor(y))
+    const int32_t* sorted;          // per pair `stride` right keypoint indices
+    int rband;                      // a band never reaches further than this many rows from floor(y)
     int classic;                    // Frame::ComputeStereoMatches: row test of :1031-1033, no disparity here
     int init_outputs;               // u_right = depth = listed = -1 for every left keypoint first
     int median_cut;
 };
 
+// The reference's row table (mvRowIndices) lists, per image row, the right keypoints whose band covers it; here
+// the right keypoints of a pair are only ordered by their own row, clamp(floor(y)) -- a counting sort in LDS --
+// and a left keypoint then looks at the rows within `rband` of its own: every right keypoint whose band
+// covers the left keypoint's row is among them (|row - y| <= r + 1 <= rband), and the exact band test
+// picks those.  One workgroup per pair; dynamic LDS: 2 * (nrows + 1) ints.
+__global__ __launch_bounds__(256) void k_stereo_rows(const orbx_keypoint* __restrict__ kr, const int32_t* __restrict__ nr_arr,
+                                                     int stride, int nrows, int32_t* __restrict__ row_start,
+                                                     int32_t* __restrict__ sorted)
+{
+    extern __shared__ int s_rows[];          // [0, nrows]: counts, then cursors; [nrows + 1, 2 nrows + 1]: offsets
+    __shared__ int s_part[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int nr = min(nr_arr[b], stride);
+    kr += (size_t)b * stride;
+    row_start += (size_t)b * (nrows + 1);
+    sorted += (size_t)b * stride;
+    int* cnt = s_rows;
+    int* offs = s_rows + nrows + 1;
+    for (int i = tid; i <= nrows; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const int r = min(max((int)floorf(kr[i].y), 0), nrows - 1);
+        atomicAdd(&cnt[r], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the counts: a contiguous chunk per thread, then the chunk sums
+    const int chunk = (nrows + 256) / 256;
+    const int c0 = min(tid * chunk, nrows + 1), c1 = min(c0 + chunk, nrows + 1);
+    int sum = 0;
+    for (int i = c0; i < c1; i++) sum += cnt[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) { const int t = s_part[i]; s_part[i] = run; run += t; }
+    }
+    __syncthreads();
+    int run = s_part[tid];
+    for (int i = c0; i < c1; i++) {
+        const int t = cnt[i];
+        offs[i] = run;
+        row_start[i] = run;
+        run += t;
+    }
+    __syncthreads();
+    for (int i = tid; i <= nrows; i += 256) cnt[i] = offs[i];
+    __syncthreads();
+    for (int i = tid; i < nr; i += 256) {
+        const int r = min(max((int)floorf(kr[i].y), 0), nrows - 1);
+        sorted[atomicAdd(&cnt[r], 1)] = i;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc)
 {
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int nl = min(a.nl[b], a.stride), nr = min(a.nr[b], a.stride);
+    const int nl = min(a.nl[b], a.stride);
     if (iL >= nl) return;
     const size_t o = (size_t)b * a.stride + iL;
     if (a.init_outputs && lane == 0) {
@@ -487,7 +544,11 @@ __global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc)
         const orbx_keypoint* kr = a.kr + (size_t)b * a.stride;
         const uint32_t* dr = a.dr + (size_t)b * a.stride * 8;
         const float last_row = (float)(a.nrows - 1);
-        for (int iR = lane; iR < nr; iR += 64) {
+        const int32_t* rs = a.row_start + (size_t)b * (a.nrows + 1);
+        const int32_t* sx = a.sorted + (size_t)b * a.stride;
+        const int k0 = rs[max(row - a.rband, 0)], k1 = rs[min(row + a.rband + 1, a.nrows)];
+        for (int kk = k0 + lane; kk < k1; kk += 64) {
+            const int iR = sx[kk];
             const float yR = kr[iR].y, uR = kr[iR].x;
             const int oR = kr[iR].octave;
             const float r = __fmul_rn(2.0f, sc.v[min(max(oR, 0), kMaxLevels - 1)]);
@@ -715,6 +776,17 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
     if (tid == 0) nmatched[b] = s_nacc;
 }
 
+// rows a band can reach from floor(y): r = 2 * scaleFactor[octave] (include/Frame.h:240), floor / ceil add one
+static int stereo_rband(const float* scale8)
+{
+    float m = 1.0f;
+    for (int i = 0; i < kMaxLevels; i++) m = scale8[i] > m ? scale8[i] : m;
+    return (int)ceilf(2.0f * m) + 1;
+}
+
+// ints of scratch the row ordering of one launch needs: per pair nrows + 1 offsets and `stride` indices
+size_t stereo_rows_ints(int nbatch, int stride, int nrows) { return (size_t)nbatch * ((size_t)nrows + 1 + (size_t)stride); }
+
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s)
 {
     ScaleTab sc;
@@ -727,6 +799,9 @@ void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t
     a.stride = L.stride; a.nrows = L.nrows; a.th_orb_dist = L.th_orb_dist;
     a.mbf = L.mbf; a.mb = L.mb; a.min_x = L.min_x;
     a.classic = 0; a.init_outputs = L.init_outputs; a.median_cut = L.median_cut;
+    a.row_start = L.d_rows; a.sorted = L.d_rows + (size_t)L.nbatch * (L.nrows + 1); a.rband = stereo_rband(scale8);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(L.nbatch), dim3(256), (size_t)(2 * (L.nrows + 1)) * 4, s, L.d_kr, L.d_nr, L.stride,
+                       L.nrows, L.d_rows, L.d_rows + (size_t)L.nbatch * (L.nrows + 1));
     hipLaunchKernelGGL(k_stereo_scan, dim3((L.stride + 3) / 4, L.nbatch), dim3(256), 0, s, a, sc);
     hipLaunchKernelGGL(k_stereo_finish, dim3(L.nbatch), dim3(256), 0, s, a);
 }
@@ -736,7 +811,7 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
                            int nbatch, int stride, const uint8_t* pyrL, const uint8_t* pyrR, const FrameGeom& g,
                            const float* scale8, const float* inv_scale8, float mbf, float mb,
                            int32_t* d_best_idx, int32_t* d_best_dist, float* d_u_right, float* d_depth,
-                           int32_t* d_nmatched, hipStream_t s)
+                           int32_t* d_nmatched, int32_t* d_rows, hipStream_t s)
 {
     ScaleTab sc, isc;
     for (int i = 0; i < kMaxLevels; i++) { sc.v[i] = scale8[i]; isc.v[i] = inv_scale8[i]; }
@@ -749,6 +824,9 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
     a.stride = stride; a.nrows = nrows; a.th_orb_dist = 75;
     a.mbf = mbf; a.mb = mb; a.min_x = 0.0f;
     a.classic = 1; a.init_outputs = 1; a.median_cut = 0;
+    a.row_start = d_rows; a.sorted = d_rows + (size_t)nbatch * (nrows + 1); a.rband = stereo_rband(scale8);
+    hipLaunchKernelGGL(k_stereo_rows, dim3(nbatch), dim3(256), (size_t)(2 * (nrows + 1)) * 4, s, d_kr, d_nr, stride, nrows,
+                       d_rows, d_rows + (size_t)nbatch * (nrows + 1));
     hipLaunchKernelGGL(k_stereo_scan, dim3((stride + 3) / 4, nbatch), dim3(256), 0, s, a, sc);
     hipLaunchKernelGGL(k_stereo_sad, dim3(nbatch), dim3(256), 0, s, d_kl, d_nl, d_kr, stride, pyrL, pyrR, g, sc, isc,
                        mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);

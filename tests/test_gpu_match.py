@@ -287,19 +287,19 @@ def _assert_stereo_state(sf_gpu, sf_orc, step):
     assert np.array_equal(sf_gpu.best_dist[:n][scanned], sf_orc.best_dist[:n][scanned]), step
 
 
-@pytest.mark.parametrize("n,seed", [(1000, 1), (5000, 2), (37, 3)])
-def test_stereo_delayed_matching(ex, matcher, oracle, n, seed):
+@pytest.mark.parametrize("n,seed,w,h", [(1000, 1, 752, 480), (5000, 2, 752, 480), (37, 3, 752, 480), (8000, 4, 3840, 2160)])
+def test_stereo_delayed_matching(ex, matcher, oracle, n, seed, w, h):
     """The default build's stereo flow (DELAYED_STEREO_MATCHING): PrepareStereoCandidates, an online
     call restricted to keypoints with map points and narrowed disparity windows, single-point calls,
     then the offline call with the median cut over everything listed so far.  5000 keypoints per
     image is beyond what the first stereo kernel accepted."""
     from orb_slam_amd import StereoFrame
     rng = np.random.default_rng(seed)
-    kl, dl, kr, dr = _random_stereo_sets(rng, n)
+    kl, dl, kr, dr = _random_stereo_sets(rng, n, w, h)
     sf = ex.GetScaleFactors()
     mbf, mb, min_x = 47.9, 0.11, 3.5
-    g = StereoFrame(matcher, kl, dl, kr, dr, 480, mbf, mb, min_x)
-    o = oracle.stereo_frame(kl, dl, kr, dr, sf, 480, mbf, mb, min_x)
+    g = StereoFrame(matcher, kl, dl, kr, dr, h, mbf, mb, min_x)
+    o = oracle.stereo_frame(kl, dl, kr, dr, sf, h, mbf, mb, min_x)
     _assert_stereo_state(g, o, "prepare")
     # tracker state: 40 % of the left keypoints have a map point; 3/4 of those project with a usable prior
     has_mp = (rng.random(n) < 0.4).astype(np.uint8)

@@ -1059,6 +1059,24 @@ __device__ __forceinline__ void lds_excl_scan2(int* a, int na, int* b, int nb, i
 // One workgroup per (level, frame).
 // ---------------------------------------------------------------------------
 struct QNode { short x0, x1, y0, y1; };
+// ctr[idx] += 1 from every calling lane.  Keys are listed cell by cell, so the lanes of a wavefront mostly sit in the
+// same node and quadrant, and LDS atomics on one address run one lane at a time: the lanes that share the first
+// lane's counter add once, together (up to three rounds), the rest add on their own.
+__device__ __forceinline__ void wave_count(int* ctr, int idx)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    bool todo = true;
+    for (int it = 0; it < 3; it++) {
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(todo);
+        if (!act) return;
+        const int leader = (int)__ffsll((long long)act) - 1;
+        const int lidx = __builtin_amdgcn_readlane(idx, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(todo && idx == lidx);
+        if (lane == leader) atomicAdd(&ctr[lidx], (int)__popcll(same));
+        todo = todo && idx != lidx;
+    }
+    if (todo) atomicAdd(&ctr[idx], 1);
+}
 // bytes of the node arrays in LDS for M nodes (the cell-offset array follows them)
 __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
 {
@@ -1079,7 +1097,10 @@ __device__ __forceinline__ int ceil_half(int d)
 // arrays of up to 2048 nodes live in LDS.  NB = 14: levels asked for more features than that keep the same arrays
 // in a per-workgroup slice of global memory (gscratch): far slower, but the result is the same and no setting is refused
 // up to 16376 features on one level.
-template <int NT, int KR, int NB>
+// UF = keys beyond the register keys that a thread loads before it works on them (levels of large frames have far more
+// candidates than registers hold: a 3840x2160 frame brings 80 000 to level 0, and a loop of one dependent load per key
+// and pass is bound by the load latency).
+template <int NT, int KR, int NB, int UF = 1>
 __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t* __restrict__ cell_cand,
                                                   const int* __restrict__ cell_count, int* __restrict__ cell_off,
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
@@ -1120,7 +1141,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     const int N = L.nfeat;
     const int ncell = L.nCols * L.nRows;
     const int* ccount = cell_count + (size_t)f * g.ncells + L.cell_base;
-    int* coff = cell_off + (size_t)f * g.ncells + L.cell_base;
+    (void)cell_off;
     const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
     uint32_t* kxy = key_xy + (size_t)f * g.keys_per_frame + L.key_base;
     uint8_t* kresp = key_resp + (size_t)f * g.keys_per_frame + L.key_base;
@@ -1128,7 +1149,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 
     // ---- gather the cells' lists into one list in the reference's append order:
     // exclusive scan of the cell counts, then one thread per key finds its cell by
-    // binary search over the offsets (kept in LDS when they fit).
+    // binary search over the offsets when they fit in LDS; otherwise the owner of a cell copies its list.
     int n;
     int* s_off = reinterpret_cast<int*>(smem + quadtree_fixed_lds(M));    // ncell + 1 entries, if off_in_lds
     {
@@ -1138,8 +1159,22 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         for (int c = b; c < e; c++) s += ccount[c];
         int base = block_excl_scan<NT>(s, s_tmp, &n);
         for (int c = b; c < e; c++) {
-            if (off_in_lds) s_off[c] = base; else coff[c] = base;
-            base += ccount[c];
+            const int cnt = ccount[c];
+            if (off_in_lds) {
+                s_off[c] = base;
+            } else {
+                // Too many cells for their offsets to fit in LDS (large frames): the thread that owns the cell copies
+                // its list straight to the key arrays, instead of one binary search through global memory per key.
+                const int ci = L.nCols > 1 ? (int)__umulhi((uint32_t)c, L.rcp_ncols) : c, cj = c - __mul24(ci, L.nCols);
+                const int x0 = __mul24(cj, L.wCell) + 3, y0 = __mul24(ci, L.hCell) + 3;
+                const uint32_t* src = cands + (uint32_t)__mul24(c, L.cell_cap);
+                for (int j = 0; j < cnt; j++) {
+                    const uint32_t u = src[j];
+                    kxy[base + j] = (uint32_t)(x0 + (int)((u >> 8) & 0xff)) | ((uint32_t)(y0 + (int)(u >> 16)) << 16);
+                    kresp[base + j] = (uint8_t)(u & 0xff);
+                }
+            }
+            base += cnt;
         }
         if (tid == NT - 1) { if (off_in_lds) s_off[ncell] = n; }
         __syncthreads();
@@ -1155,11 +1190,10 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         int lo = 0, hi = ncell;                 // largest c with off[c] <= i
         while (hi - lo > 1) {
             const int mid = (lo + hi) >> 1;
-            const int o = off_in_lds ? s_off[mid] : coff[mid];
-            if (o <= i) lo = mid; else hi = mid;
+            if (s_off[mid] <= i) lo = mid; else hi = mid;
         }
         const int c = lo;
-        const int o = off_in_lds ? s_off[c] : coff[c];
+        const int o = s_off[c];
         // small operands: 24-bit multiplies and a reciprocal instead of 32-bit multiplies and a division
         const uint32_t u = cands[(uint32_t)(__mul24(c, L.cell_cap) + (i - o))];
         const int ci = L.nCols > 1 ? (int)__umulhi((uint32_t)c, L.rcp_ncols) : c, cj = c - __mul24(ci, L.nCols);
@@ -1176,14 +1210,21 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         rxy[k] = 0u;
         rnode[k] = 0u;
         if (i < n) {
-            uint32_t resp;
-            fetch_key(i, rxy[k], resp);
-            rnode[k] = resp << 16;
+            if (off_in_lds) {
+                uint32_t resp;
+                fetch_key(i, rxy[k], resp);
+                rnode[k] = resp << 16;
+            } else {
+                rxy[k] = kxy[i];
+                rnode[k] = (uint32_t)kresp[i] << 16;
+            }
         }
     }
     for (int i = tid + NT * KR; i < n; i += NT) {
-        uint32_t xy, resp;
-        fetch_key(i, xy, resp);
+        if (off_in_lds) {
+            uint32_t xy, resp;
+            fetch_key(i, xy, resp);
+        }
         knode[i] = 0;
     }
     __syncthreads();
@@ -1199,13 +1240,24 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             rnode[k_] = (nd & 0xffffu) | (resp << 16);                          \
         }                                                                       \
     }                                                                           \
-    for (int i = tid + NT * KR; i < n; i += NT) {                       \
-        const uint32_t xy = kxy[i];                                             \
-        uint32_t nd = knode[i];                                                 \
-        const uint32_t resp = kresp[i];                                         \
-        (void)xy; (void)resp;                                                   \
-        __VA_ARGS__;                                                            \
-        knode[i] = (uint16_t)nd;                                                \
+    for (int i0_ = tid + NT * KR; i0_ < n; i0_ += NT * UF) {                    \
+        uint32_t oxy_[UF], ond_[UF], ors_[UF];                                  \
+        _Pragma("unroll") for (int u_ = 0; u_ < UF; u_++) {                   \
+            const int i = i0_ + NT * u_;                                        \
+            oxy_[u_] = 0u; ond_[u_] = 0u; ors_[u_] = 0u;                        \
+            if (i < n) { oxy_[u_] = kxy[i]; ond_[u_] = knode[i]; ors_[u_] = kresp[i]; } \
+        }                                                                       \
+        _Pragma("unroll") for (int u_ = 0; u_ < UF; u_++) {                   \
+            const int i = i0_ + NT * u_;                                        \
+            if (i < n) {                                                        \
+                const uint32_t xy = oxy_[u_];                                   \
+                uint32_t nd = ond_[u_];                                         \
+                const uint32_t resp = ors_[u_];                                 \
+                (void)xy; (void)resp;                                           \
+                __VA_ARGS__;                                                    \
+                knode[i] = (uint16_t)nd;                                        \
+            }                                                                   \
+        }                                                                       \
     }
 
     // ---- root nodes (:492-534)
@@ -1285,7 +1337,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
                 int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
                 int qd = (x < q.x0 + hx ? 0 : 1) + (y < q.y0 + hy ? 0 : 2);
-                atomicAdd(&s_cc[4 * p + qd], 1);
+                // levels with very many keys (large frames) are bound by same-address LDS atomics; ordinary levels are not
+                if (UF > 1 && n > 8192) wave_count(&s_cc[0], 4 * p + qd);
+                else atomicAdd(&s_cc[4 * p + qd], 1);
                 nd = (uint32_t)(p | (qd << NB));
             }
         })
@@ -1436,11 +1490,11 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 // the throughput shape for batches.  1024 threads x 3 register keys shortens the per-key passes of
 // a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
 __global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs, 11>(QUADTREE_ARGS); }
-__global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 11>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 11, 8>(QUADTREE_ARGS); }
 // 512 threads x 5 register keys: between the two, for batches that fill the device only once
 __global__ __launch_bounds__(512) void k_quadtree_mid(QUADTREE_PARAMS) { quadtree_body<512, 5, 11>(QUADTREE_ARGS); }
 // more than 2048 nodes on a level: node arrays in global memory
-__global__ __launch_bounds__(1024) void k_quadtree_big(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 14>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(1024) void k_quadtree_big(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 14, 8>(QUADTREE_ARGS); }
 #undef QUADTREE_ARGS
 #undef QUADTREE_PARAMS
 

@@ -248,16 +248,27 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void blur_hsum4w(uint32_t Lw, uint32_t Cw, uint32_t Rw, uint32_t out[4])
 {
-    // (Lw, Cw, Rw) = 12 bytes: pixels x-4 .. x+7 of one row; pixel j's window = bytes j+1 .. j+7
-    const uint32_t K0 = 18u | (34u << 8) | (49u << 16) | (55u << 24);   // taps 0..3
-    const uint32_t K1 = 49u | (34u << 8) | (18u << 16);                 // taps 4..6
-    out[0] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 1), K1,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 1), K0, 0u, false), false);
-    out[1] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 2), K1,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 2), K0, 0u, false), false);
-    out[2] = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Rw, Cw, 3), K1,
-                                    __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(Cw, Lw, 3), K0, 0u, false), false);
-    out[3] = __builtin_amdgcn_udot4(Rw, K1, __builtin_amdgcn_udot4(Cw, K0, 0u, false), false);
+    // (Lw, Cw, Rw) = 12 bytes: pixels x-4 .. x+7 of one row; pixel j's window = bytes j+1 .. j+7.  The three dwords stay as
+    // they are and the taps are shifted instead: 10 four-term dot products, no byte alignment.
+    constexpr uint32_t w0 = 18u, w1 = 34u, w2 = 49u, w3 = 55u, w4 = 49u, w5 = 34u, w6 = 18u;
+    out[0] = __builtin_amdgcn_udot4(Cw, w3 | (w4 << 8) | (w5 << 16) | (w6 << 24),
+                                    __builtin_amdgcn_udot4(Lw, (w0 << 8) | (w1 << 16) | (w2 << 24), 0u, false), false);
+    out[1] = __builtin_amdgcn_udot4(Rw, w6,
+                                    __builtin_amdgcn_udot4(Cw, w2 | (w3 << 8) | (w4 << 16) | (w5 << 24),
+                                                           __builtin_amdgcn_udot4(Lw, (w0 << 16) | (w1 << 24), 0u, false), false), false);
+    out[2] = __builtin_amdgcn_udot4(Rw, w5 | (w6 << 8),
+                                    __builtin_amdgcn_udot4(Cw, w1 | (w2 << 8) | (w3 << 16) | (w4 << 24),
+                                                           __builtin_amdgcn_udot4(Lw, w0 << 24, 0u, false), false), false);
+    out[3] = __builtin_amdgcn_udot4(Rw, w4 | (w5 << 8) | (w6 << 16),
+                                    __builtin_amdgcn_udot4(Cw, w0 | (w1 << 8) | (w2 << 16) | (w3 << 24), 0u, false), false);
+}
+
+// two signed 16-bit integers -> two bytes with unsigned saturation, in the low half of the result
+__device__ __forceinline__ uint32_t sat_pk_u8(uint32_t pair)
+{
+    uint32_t r;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(r) : "v"(pair));
+    return r;
 }
 
 __device__ __forceinline__ void blur_hsum4(const uint8_t* p, uint32_t out[4])
@@ -340,12 +351,13 @@ __device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 5) % 6][j]), W45, s, false);
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 3) % 6][j]), W23, s, false);
                 s = __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, P[(p + 1) % 6][j]), W01, s, false);
-                acc[j] = min(s, 0x00ffffffu);            // byte 2 = min(255, s >> 16)
+                acc[j] = s;
                 P[p][j] = hprev[j] | (hc[j] << 16);
                 hprev[j] = hc[j];
             }
-            const uint32_t lo = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u);
-            const uint32_t hi = __builtin_amdgcn_perm(acc[3], acc[2], 0x0c0c0602u);
+            // s >> 16 is at most 257: the high halves of two sums as a pair of 16-bit integers, saturated to two bytes
+            const uint32_t lo = sat_pk_u8(__builtin_amdgcn_perm(acc[1], acc[0], 0x07060302u));
+            const uint32_t hi = sat_pk_u8(__builtin_amdgcn_perm(acc[3], acc[2], 0x07060302u));
             *reinterpret_cast<uint32_t*>(dst + (size_t)(dofs + __umul24((uint32_t)p, pitch))) = lo | (hi << 16);
         }
     }

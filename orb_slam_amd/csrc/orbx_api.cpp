@@ -1211,7 +1211,6 @@ int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* 
     if (!d_kl || !d_dl || !d_nl || !d_kr || !d_dr || !d_nr || !d_best_idx || !d_best_dist || !d_u_right || !d_depth || !d_nmatched)
         return fail(c, ORBX_ERR_INVALID, "null buffer");
     if (nbatch < 1 || stride < 1) return fail(c, ORBX_ERR_INVALID, "bad sizes");
-    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per image");
     if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
     if (c->device != r->device) return fail(c, ORBX_ERR_INVALID, "left and right contexts are on different devices");
     if (!c->have_pyramid || !r->have_pyramid) return fail(c, ORBX_ERR_STATE, "both contexts need a computed pyramid");
@@ -1226,7 +1225,7 @@ int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* 
         HIPCHECK(c, hipStreamWaitEvent(c->stream, c->ev_pyr, 0));
     }
     {
-        const size_t need = stereo_rows_ints(nbatch, stride, c->g.lv[0].h) * 4;
+        const size_t need = stereo_classic_ints(nbatch, stride, c->g.lv[0].h) * 4;
         if (need > c->stereo_rows.bytes) {
             HIPCHECK(c, finish(c));
             HIPCHECK(c, c->stereo_rows.ensure(need));
@@ -1294,7 +1293,6 @@ int orbx_stereo_match_sad(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* kl, con
 static int grid_prepare(orbx_ctx* c, const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch,
                         float min_x, float min_y, float inv_w, float inv_h)
 {
-    if (stride > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
     const size_t need_s = (size_t)nbatch * (kFrameGridCells + 1) * 4, need_l = (size_t)nbatch * stride * 4;
     if (need_s > c->grid_start.bytes || need_l > c->grid_list.bytes) {
         HIPCHECK(c, finish(c));
@@ -1362,7 +1360,6 @@ int orbx_grid_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc
     if (N < 0 || Q < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
     if (Q == 0) return ORBX_OK;
     if (!qdesc || !best_idx || !best_dist || !second_dist || (N > 0 && !desc)) return fail(c, ORBX_ERR_INVALID, "null buffer");
-    if (N > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
     int rc = grid_upload(c, kps, desc, N, qx, qy, qr, qmin, qmax, qdesc, Q);
     if (rc != ORBX_OK) return rc;
     const int stride = N > 0 ? N : 1;
@@ -1394,7 +1391,6 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
     if (N < 0 || Q < 0 || !cand_off) return fail(c, ORBX_ERR_INVALID, "bad arguments");
     cand_off[0] = 0;
     if (Q == 0) return ORBX_OK;
-    if (N > 4096) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 4096 keypoints per frame");
     int rc = grid_upload(c, kps, nullptr, N, qx, qy, qr, qmin, qmax, nullptr, Q);
     if (rc != ORBX_OK) return rc;
     const int stride = N > 0 ? N : 1;

@@ -83,6 +83,7 @@ struct StereoLaunch {
 };
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s);
 size_t stereo_rows_ints(int nbatch, int stride, int nrows);
+size_t stereo_classic_ints(int nbatch, int stride, int nrows);
 
 void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, const int32_t* d_nl,
                            const orbx_keypoint* d_kr, const uint32_t* d_dr, const int32_t* d_nr,

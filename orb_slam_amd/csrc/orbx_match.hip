@@ -642,8 +642,6 @@ __global__ __launch_bounds__(256) void k_stereo_finish(StereoArgs a)
     if (tid == 0) a.nmatched[b] = s_scanned - s_removed;
 }
 
-constexpr int kStereoMaxRight = 4096;    // keypoints per image of the SAD refinement and of the frame grid (LDS lists)
-
 // ---------------------------------------------------------------------------
 // Classic stereo refinement, Frame::ComputeStereoMatches src/Frame.cc:1070-1172:
 // for every left keypoint whose Hamming match is below 75, an 11x11 SAD window
@@ -652,6 +650,9 @@ constexpr int kStereoMaxRight = 4096;    // keypoints per image of the SAD refin
 // 2.1 x the median SAD.  One workgroup per stereo pair; one wavefront per
 // accepted keypoint at a time: work item (row dy, shift incR) sums |a-b| over the
 // 11 columns, 11 lanes then add the rows.  All sums are exact integers.
+// The pair's lists (keypoints to refine, accepted SADs and their keypoints) live in `lists`,
+// 3 * stride ints per pair of device memory, so the number of keypoints is not limited; the median
+// (element nacc / 2 in ascending order, :1159-1160) is found by two 256-bin histograms (an SAD is below 2^16).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restrict__ kl, const int32_t* __restrict__ nl_arr,
                                                     const orbx_keypoint* __restrict__ kr, int stride,
@@ -659,15 +660,16 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
                                                     FrameGeom g, ScaleTab sc, ScaleTab inv_sc, float mbf, float mb,
                                                     const int32_t* __restrict__ best_idx, const int32_t* __restrict__ best_dist,
                                                     float* __restrict__ u_right, float* __restrict__ depth,
-                                                    int32_t* __restrict__ nmatched)
+                                                    int32_t* __restrict__ nmatched, int32_t* __restrict__ lists)
 {
-    __shared__ unsigned short s_list[kStereoMaxRight];      // left keypoints with a Hamming match < 75
-    __shared__ int s_sad[kStereoMaxRight];                  // accepted: best SAD
-    __shared__ unsigned short s_acc[kStereoMaxRight];       // accepted: left index
+    __shared__ int s_hist[256];
     __shared__ int s_part[4][128];
-    __shared__ int s_nlist, s_nacc, s_median;
+    __shared__ int s_nlist, s_nacc, s_median, s_bin, s_rank;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nl = min(nl_arr[b], min(stride, kStereoMaxRight));
+    const int nl = min(nl_arr[b], stride);
+    int32_t* s_list = lists + (size_t)b * 3 * stride;       // left keypoints with a Hamming match < 75
+    int32_t* s_sad = s_list + stride;                       // accepted: best SAD
+    int32_t* s_acc = s_sad + stride;                        // accepted: left index
     kl += (size_t)b * stride; kr += (size_t)b * stride;
     best_idx += (size_t)b * stride; best_dist += (size_t)b * stride;
     u_right += (size_t)b * stride; depth += (size_t)b * stride;
@@ -675,7 +677,7 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
     if (tid == 0) { s_nlist = 0; s_nacc = 0; }
     __syncthreads();
     for (int iL = tid; iL < nl; iL += 256)
-        if (best_idx[iL] >= 0 && best_dist[iL] < 75) s_list[atomicAdd(&s_nlist, 1)] = (unsigned short)iL;
+        if (best_idx[iL] >= 0 && best_dist[iL] < 75) s_list[atomicAdd(&s_nlist, 1)] = iL;
     __syncthreads();
     const int nlist = s_nlist;
     const float minD = 0.0f, maxD = __fdiv_rn(mbf, mb);
@@ -740,25 +742,37 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
                     u_right[iL] = bestuR;
                     const int slot = atomicAdd(&s_nacc, 1);
                     s_sad[slot] = bestSad;
-                    s_acc[slot] = (unsigned short)iL;
+                    s_acc[slot] = iL;
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    // median = element nacc/2 of the list sorted by (SAD, left index), :1159-1160
+    // median = SAD of element nacc/2 of the list sorted by (SAD, left index), :1159-1160: the bin of the high byte that
+    // holds that rank, then the low byte inside the bin
     const int nacc = s_nacc;
-    if (tid == 0) s_median = -1;
-    __syncthreads();
-    for (int i = tid; i < nacc; i += 256) {
-        const int di = s_sad[i], ii = s_acc[i];
-        int rank = 0;
-        for (int j = 0; j < nacc; j++) {
-            const int dj = s_sad[j];
-            rank += (dj < di) || (dj == di && s_acc[j] < ii);
+    if (tid == 0) { s_median = -1; s_bin = 0; s_rank = nacc / 2; }
+    for (int pass = 0; pass < 2 && nacc > 0; pass++) {
+        s_hist[tid] = 0;
+        __syncthreads();
+        const int bin = s_bin;
+        for (int i = tid; i < nacc; i += 256) {
+            const int di = min(s_sad[i], 0xffff);
+            if (pass == 0) atomicAdd(&s_hist[di >> 8], 1);
+            else if ((di >> 8) == bin) atomicAdd(&s_hist[di & 255], 1);
         }
-        if (rank == nacc / 2) s_median = di;
+        __syncthreads();
+        if (tid == 0) {
+            int cum = 0, k = 0;
+            for (; k < 255; k++) {
+                if (cum + s_hist[k] > s_rank) break;
+                cum += s_hist[k];
+            }
+            if (pass == 0) { s_bin = k; s_rank -= cum; }
+            else s_median = (bin << 8) | k;
+        }
+        __syncthreads();
     }
     __syncthreads();
     int removed = 0;
@@ -786,6 +800,8 @@ static int stereo_rband(const float* scale8)
 
 // ints of scratch the row ordering of one launch needs: per pair nrows + 1 offsets and `stride` indices
 size_t stereo_rows_ints(int nbatch, int stride, int nrows) { return (size_t)nbatch * ((size_t)nrows + 1 + (size_t)stride); }
+// ints of scratch of the classic flow: the row ordering, then the three lists of the SAD refinement per pair
+size_t stereo_classic_ints(int nbatch, int stride, int nrows) { return stereo_rows_ints(nbatch, stride, nrows) + (size_t)nbatch * 3 * (size_t)stride; }
 
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s)
 {
@@ -829,7 +845,8 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
                        d_rows, d_rows + (size_t)nbatch * (nrows + 1));
     hipLaunchKernelGGL(k_stereo_scan, dim3((stride + 3) / 4, nbatch), dim3(256), 0, s, a, sc);
     hipLaunchKernelGGL(k_stereo_sad, dim3(nbatch), dim3(256), 0, s, d_kl, d_nl, d_kr, stride, pyrL, pyrR, g, sc, isc,
-                       mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched);
+                       mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched,
+                       d_rows + stereo_rows_ints(nbatch, stride, nrows));
 }
 
 // ---------------------------------------------------------------------------
@@ -848,24 +865,22 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbx_keypoint* __restr
                                                     int* __restrict__ cell_start, int* __restrict__ cell_list)
 {
     __shared__ int s_cnt[kGridCells];
-    __shared__ short s_cell[kStereoMaxRight];
     __shared__ int s_wsum[4];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int n = min(n_arr ? n_arr[b] : N, min(stride, kStereoMaxRight));
+    const int n = min(n_arr ? n_arr[b] : N, stride);
     kps += (size_t)b * stride;
     cell_start += (size_t)b * (kGridCells + 1);
     cell_list += (size_t)b * stride;
+    auto cell_of = [&](int i) -> int {
+        const int posX = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, minX), invW));
+        const int posY = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, minY), invH));
+        return (posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows) ? -1 : posX * kGridRows + posY;
+    };
     for (int c = tid; c < kGridCells; c += 256) s_cnt[c] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
-        const int posX = (int)roundf(__fmul_rn(__fsub_rn(kps[i].x, minX), invW));
-        const int posY = (int)roundf(__fmul_rn(__fsub_rn(kps[i].y, minY), invH));
-        int c = -1;
-        if (!(posX < 0 || posX >= kGridCols || posY < 0 || posY >= kGridRows)) {
-            c = posX * kGridRows + posY;
-            atomicAdd(&s_cnt[c], 1);
-        }
-        s_cell[i] = (short)c;
+        const int c = cell_of(i);
+        if (c >= 0) atomicAdd(&s_cnt[c], 1);
     }
     __syncthreads();
     // exclusive scan of the 3072 counts: 12 per thread
@@ -881,16 +896,29 @@ __global__ __launch_bounds__(256) void k_grid_build(const orbx_keypoint* __restr
     int base = incl - sum;
     for (int w = 0; w < wave; w++) base += s_wsum[w];
     __syncthreads();
+    const int first = base;
 #pragma unroll
     for (int k = 0; k < 12; k++) { s_cnt[tid * 12 + k] = base; cell_start[tid * 12 + k] = base; base += local[k]; }
     if (tid == 255) cell_start[kGridCells] = base;
     __syncthreads();
+    // scatter in any order, then every thread puts the short lists of its 12 cells into ascending keypoint
+    // order (the push_back order of the reference)
     for (int i = tid; i < n; i += 256) {
-        const int c = s_cell[i];
-        if (c < 0) continue;
-        int rank = 0;
-        for (int j = 0; j < i; j++) rank += (s_cell[j] == c);
-        cell_list[s_cnt[c] + rank] = i;
+        const int c = cell_of(i);
+        if (c >= 0) cell_list[atomicAdd(&s_cnt[c], 1)] = i;
+    }
+    __syncthreads();
+    int lo = first;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        const int hi = lo + local[k];
+        for (int a = lo + 1; a < hi; a++) {
+            const int v = cell_list[a];
+            int p = a - 1;
+            while (p >= lo && cell_list[p] > v) { cell_list[p + 1] = cell_list[p]; p--; }
+            cell_list[p + 1] = v;
+        }
+        lo = hi;
     }
 }
 

@@ -210,6 +210,31 @@ def test_stereo_classic_sad_refinement(ex, matcher):
     exr.close()
 
 
+def test_stereo_classic_sad_many_keypoints(matcher):
+    """The same with more than 4096 keypoints per image (the lists of the refinement live in device memory)."""
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    from oracle_lib import Oracle
+    w, h, nfeat = 1600, 1200, 9000
+    exl, exr = ORBextractor(nfeat, 1.2, 8, 8, 3), ORBextractor(nfeat, 1.2, 8, 8, 3)      # low FAST thresholds: many corners
+    ol, orr = Oracle(nfeat, 1.2, 8, 8, 3), Oracle(nfeat, 1.2, 8, 8, 3)
+    left, right = synthetic_stereo_pair(w, h, 99)
+    kl, dl = exl(left)
+    kr, dr = exr(right)
+    kl_o, dl_o = ol.extract(left)
+    kr_o, dr_o = orr.extract(right)
+    assert np.array_equal(kl, kl_o) and np.array_equal(kr, kr_o)
+    assert len(kl) > 4096 and len(kr) > 4096
+    mbf, mb = 90.0, 0.11
+    bi, bd, ur, dp, nm = ORBmatcher(exl).stereo_match_sad(exr, kl, dl, kr, dr, mbf, mb)
+    oi, od, our, odp, onm = ol.stereo_classic(orr, kl, dl, kr, dr, mbf, mb)
+    assert np.array_equal(bi, oi) and np.array_equal(bd, od)
+    assert nm == onm
+    assert np.array_equal(ur, our) and np.array_equal(dp, odp)
+    assert (ur >= 0).sum() > 500
+    exl.close()
+    exr.close()
+
+
 def _grid_queries(rng, kps, Q):
     pick = rng.integers(0, len(kps), Q)
     qx = (kps["x"][pick] + rng.normal(0, 6, Q)).astype(np.float32)
@@ -249,6 +274,31 @@ def test_grid_candidates_and_fused_search(ex, matcher, oracle, euroc_left):
     off_o, idx_o = oracle.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
     off_g, idx_g = matcher.features_in_area(k2, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
     assert np.array_equal(off_g, off_o) and np.array_equal(idx_g, idx_o)
+
+
+def test_grid_many_keypoints(matcher, oracle):
+    """more than 4096 keypoints in one frame grid, with crowded cells (long per-cell lists keep index order)"""
+    rng = np.random.default_rng(5)
+    n = 9000
+    kps = np.zeros(n, KP_DTYPE)
+    kps["x"] = rng.uniform(0, 752, n).astype(np.float32)
+    kps["y"] = rng.uniform(0, 480, n).astype(np.float32)
+    kps["x"][:1500] = rng.uniform(100, 112, 1500).astype(np.float32)          # 1500 keypoints in one or two cells
+    kps["y"][:1500] = rng.uniform(200, 210, 1500).astype(np.float32)
+    kps["octave"] = rng.integers(0, 8, n)
+    desc = random_descriptors(n, 11)
+    min_x, min_y = 0.0, 0.0
+    inv_w, inv_h = float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480))
+    Q = 400
+    qx, qy, qr, qmin, qmax, pick = _grid_queries(rng, kps, Q)
+    off_o, idx_o = oracle.features_in_area(kps, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    off_g, idx_g = matcher.features_in_area(kps, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax)
+    assert np.array_equal(off_g, off_o) and np.array_equal(idx_g, idx_o)
+    qdesc = desc[pick].copy()
+    got = matcher.grid_search(kps, desc, min_x, min_y, inv_w, inv_h, qx, qy, qr, qmin, qmax, qdesc)
+    ref = oracle.match_windowed(qdesc, desc, off_o, idx_o, kps["octave"])
+    for g_, r_, name in zip(got[:5], ref, ["best_idx", "best_dist", "second_dist", "best_lvl", "second_lvl"]):
+        assert np.array_equal(g_, r_), name
 
 
 def _random_stereo_sets(rng, n, w=752, h=480, planted=None):

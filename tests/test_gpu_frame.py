@@ -109,3 +109,36 @@ def test_undistort_device_batch_on_extraction_output(gpu, oracle):
         # bit patterns: octave / class_id are integers stored in the float view (class_id -1 reads as NaN)
         assert np.array_equal(after[b, :n[b], 2:].view(np.int32), before[b, :n[b], 2:].view(np.int32))
         assert np.array_equal(after[b, n[b]:].view(np.int32), before[b, n[b]:].view(np.int32))   # slots past the count are untouched
+
+
+@pytest.mark.gpu
+def test_detections_written_by_the_gpu_path_replay_bit_identically(tmp_path, euroc_left, euroc_right):
+    """The detection-I/O bypass end to end (src/Frame.cc:590-609 writes, include/Util.hpp:400-449 reads): a stereo
+    pair extracted on the GPU, exported, read back as the tracker would, equals the oracle's extraction, and the
+    stereo matches computed from the replayed lists equal the oracle's."""
+    from orb_slam_amd import ORBextractor, ORBmatcher, KP_DTYPE
+    from orb_slam_amd.detection_io import ExportToYML, KeyPointLog
+    from oracle_lib import Oracle
+    exl, exr = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)
+    kl, dl = exl(euroc_left)
+    kr, dr = exr(euroc_right)
+    p = tmp_path / "frame.yml"
+    ExportToYML(p, 1403636579.763555527, kl, dl, kr, dr)
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    o = Oracle(1000, 1.2, 8, 20, 7)
+    kl_o, dl_o = o.extract(euroc_left)
+    kr_o, dr_o = o.extract(euroc_right)
+    for a, b in ((log.mvKeysLeft, kl_o), (log.mvKeysRight, kr_o)):
+        for f in KP_DTYPE.names:
+            assert np.array_equal(a[f], b[f]), f
+    assert np.array_equal(log.mDiscLeft, dl_o) and np.array_equal(log.mDiscRight, dr_o)
+    mbf, mb = 47.9, 0.11
+    got = ORBmatcher(exl).stereo_match(log.mvKeysLeft, log.mDiscLeft, log.mvKeysRight, log.mDiscRight, 480, mbf, mb, 0.0)
+    sf = o.tables()["scale"]
+    f = o.stereo_frame(kl_o, dl_o, kr_o, dr_o, sf, 480, mbf, mb, 0.0)
+    nm = f.ComputeStereoMatches_Undistorted(False)
+    assert got[4] == nm and nm > 100
+    assert np.array_equal(got[2], f.mvuRight[:len(kl_o)]) and np.array_equal(got[3], f.mvDepth[:len(kl_o)])
+    exl.close()
+    exr.close()

@@ -552,31 +552,6 @@ def main():
             del d_nat
         except FileNotFoundError:
             pass
-        # two contexts on two streams, half the batch each: what overlapping the memory-bound stages of one half with
-        # the issue-bound stages of the other is worth to a caller who arranges it (never `value`)
-        try:
-            half = B // 2
-            ex2 = ORBextractor(wl.nfeat, 1.2, 8, 20, 7, device=dev_index)
-            st2 = torch.cuda.Stream(device=dev)
-            ex2.set_stream(st2.cuda_stream)
-
-            def both():
-                ex.extract_batch_device(wl.d_imgs, half, W, H, W, W * H, wl.d_kps, wl.d_desc, wl.cap, wl.d_n)
-                ex2.extract_batch_device(wl.d_imgs[half:], B - half, W, H, W, W * H, wl.d_kps[half:], wl.d_desc[half:],
-                                         wl.cap, wl.d_n[half:])
-            settle(both, args.settle_ms / 2)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(20):
-                both()
-            barrier()
-            dt_ = (time.perf_counter() - t0) / 20
-            legs["two_contexts_two_streams"] = {"frames_per_s": round(B / dt_, 1), "ms_per_step": round(dt_ * 1e3, 4),
-                                                "what": "the same %d frames as two half-batches on two contexts and two streams" % B}
-            ex2.set_stream(None)
-            ex2.close()
-        except Exception as e:      # a leg, not the measurement
-            legs["two_contexts_two_streams"] = {"error": repr(e)}
         # host-fed batches: upload + kernels + download + synchronise per call (never `value`)
         import ctypes as C
         ex.set_stream(None)

@@ -1,0 +1,66 @@
+"""The segment test of FAST-9/16 against an implementation that shares nothing with this repository:
+scikit-image's corner_fast (n = 9), where the image has a second Python with scikit-image installed
+(/opt/conda/bin/python3.9).  It is run as a child process on crops of the reference's own test
+images and of a synthetic frame; its corner mask (before any non-maximum suppression) must equal
+"threshold-free score >= t" of the oracle for both thresholds of the extractor.  This pins the ring
+offsets, the wrap-around of the 9-arc and the strict inequality; it says nothing about scores."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+OTHER_PYTHON = "/opt/conda/bin/python3.9"
+
+CHILD = r"""
+import sys, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from skimage.feature import corner_fast
+img = np.load(sys.argv[1]).astype(np.float64)          # integers 0..255 as floats: compared as they are
+out = []
+for t in (7, 20):
+    # ring > centre + t  <=>  ring > centre + t + 0.5 on integers: no equality in floating point
+    out.append(corner_fast(img, n=9, threshold=t + 0.5) > 0)
+np.save(sys.argv[2], np.stack(out))
+"""
+
+
+def _have_other_python():
+    if not os.path.exists(OTHER_PYTHON):
+        return False
+    try:
+        r = subprocess.run([OTHER_PYTHON, "-c", "import skimage.feature"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=120)
+    except (OSError, subprocess.TimeoutExpired):
+        return False
+    return r.returncode == 0
+
+
+@pytest.mark.skipif(not _have_other_python(), reason="no second Python with scikit-image in this image")
+def test_segment_test_equals_scikit_image(oracle, euroc_left, euroc_right, tmp_path):
+    from orb_slam_amd.synth import synthetic_frame
+    crops = [euroc_left[100:260, 200:420], euroc_right[250:400, 380:600], synthetic_frame(240, 180, 4242)]
+    child = tmp_path / "child.py"
+    child.write_text(CHILD)
+    total = corners = 0
+    for k, img in enumerate(crops):
+        img = np.ascontiguousarray(img)
+        src, dst = tmp_path / ("in%d.npy" % k), tmp_path / ("out%d.npy" % k)
+        np.save(src, img)
+        subprocess.run([OTHER_PYTHON, str(child), str(src), str(dst)], check=True, timeout=300,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        masks = np.load(dst)
+        h, w = img.shape
+        score = np.zeros((h, w), np.int32)
+        for y in range(3, h - 3):
+            for x in range(3, w - 3):
+                score[y, x] = oracle.fast_score(img, x, y)
+        for mask, t in zip(masks, (7, 20)):
+            mine = score >= t
+            inner = (slice(3, h - 3), slice(3, w - 3))
+            assert np.array_equal(mine[inner], mask[inner]), "threshold %d, crop %d: %d pixels differ" % (
+                t, k, int((mine[inner] != mask[inner]).sum()))
+            corners += int(mask[inner].sum())
+        total += (h - 6) * (w - 6)
+    assert total > 90000 and corners > 300

@@ -64,3 +64,35 @@ def test_segment_test_equals_scikit_image(oracle, euroc_left, euroc_right, tmp_p
             corners += int(mask[inner].sum())
         total += (h - 6) * (w - 6)
     assert total > 90000 and corners > 300
+
+
+RESIZE_CHILD = r"""
+import sys, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from skimage.transform import resize
+img = np.load(sys.argv[1]).astype(np.float64)
+dh, dw = int(sys.argv[3]), int(sys.argv[4])
+np.save(sys.argv[2], resize(img, (dh, dw), order=1, mode="edge", anti_aliasing=False, preserve_range=True, clip=False))
+"""
+
+
+@pytest.mark.skipif(not _have_other_python(), reason="no second Python with scikit-image in this image")
+@pytest.mark.parametrize("dw,dh", [(627, 400), (522, 333)])
+def test_resize_sampling_rule_equals_scikit_image(oracle, euroc_left, tmp_path, dw, dh):
+    """cv::resize(INTER_LINEAR) samples at (x + 0.5) * scale - 0.5 with edge replication; scikit-image's order-1
+    resize without anti-aliasing is the same map evaluated in double precision.  The 11-bit fixed-point restatement
+    stays within one grey level of it (a different sampling rule, e.g. corner-aligned, is off by tens of levels
+    on a natural image)."""
+    src_img = euroc_left if dw == 627 else oracle.resize(euroc_left, 627, 400)
+    child = tmp_path / "child_resize.py"
+    child.write_text(RESIZE_CHILD)
+    src, dst = tmp_path / "in.npy", tmp_path / "out.npy"
+    np.save(src, np.ascontiguousarray(src_img))
+    subprocess.run([OTHER_PYTHON, str(child), str(src), str(dst), str(dh), str(dw)], check=True, timeout=300,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    ref = np.load(dst)
+    got = oracle.resize(src_img, dw, dh).astype(np.float64)
+    err = np.abs(got - ref)
+    assert err.max() <= 1.0, err.max()
+    assert err.mean() < 0.35

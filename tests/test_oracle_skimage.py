@@ -96,3 +96,86 @@ def test_resize_sampling_rule_equals_scikit_image(oracle, euroc_left, tmp_path, 
     err = np.abs(got - ref)
     assert err.max() <= 1.0, err.max()
     assert err.mean() < 0.35
+
+
+SKIMAGE_PATTERN = "/opt/conda/lib/python3.9/site-packages/skimage/feature/orb_descriptor_positions.txt"
+
+
+@pytest.mark.skipif(not os.path.exists(SKIMAGE_PATTERN), reason="scikit-image's copy of the rBRIEF pattern is not in this image")
+def test_rbrief_pattern_equals_scikit_image_copy(oracle):
+    """scikit-image ships its own copy of OpenCV's learned 256-pair test pattern (x0, y0, x1, y1 per row): the 1024
+    integers the oracle and the kernels use (data taken from src/ORBextractor.cc:152-410) are the same."""
+    theirs = np.loadtxt(SKIMAGE_PATTERN)
+    assert theirs.shape == (256, 4)
+    assert np.array_equal(theirs, np.rint(theirs))
+    assert np.array_equal(oracle.pattern().astype(np.int64), theirs.astype(np.int64))
+
+
+GAUSS_CHILD = r"""
+import sys, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from scipy.ndimage import gaussian_filter
+img = np.load(sys.argv[1]).astype(np.float64)
+# radius int(truncate * sigma + 0.5) = 3: seven taps exp(-x^2 / 8) normalised; 'mirror' = d c b | a b c d | c b a
+np.save(sys.argv[2], gaussian_filter(img, sigma=2.0, truncate=1.5, mode="mirror"))
+"""
+
+
+@pytest.mark.skipif(not _have_other_python(), reason="no second Python with scipy in this image")
+def test_gaussian_equals_scipy(oracle, euroc_left, tmp_path):
+    """GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) against scipy.ndimage.gaussian_filter of the second Python with the
+    same support and border rule: within one grey level once the 8.8 fixed-point taps' extra weight (257 / 256 per
+    pass) is taken into account."""
+    img = np.ascontiguousarray(euroc_left[:240, :320])
+    child = tmp_path / "child_gauss.py"
+    child.write_text(GAUSS_CHILD)
+    src, dst = tmp_path / "in.npy", tmp_path / "out.npy"
+    np.save(src, img)
+    subprocess.run([OTHER_PYTHON, str(child), str(src), str(dst)], check=True, timeout=300,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    ref = np.load(dst)
+    got = oracle.blur_bordered(np.pad(img, 3, mode="reflect"), 3).astype(np.float64)
+    assert got.shape == ref.shape
+    err = np.abs(got - np.minimum(ref * (257.0 / 256.0) ** 2, 255.0))
+    assert err.max() <= 1.0, err.max()
+    assert err.mean() < 0.3
+
+
+ORIENT_CHILD = r"""
+import sys, warnings
+warnings.filterwarnings("ignore")
+import numpy as np
+from skimage.feature import corner_orientations
+from skimage.feature.orb import OFAST_MASK
+img = np.load(sys.argv[1]).astype(np.float64)
+corners = np.load(sys.argv[2])                      # (row, col)
+np.save(sys.argv[3], corner_orientations(img, corners, OFAST_MASK))
+"""
+
+
+@pytest.mark.skipif(not _have_other_python(), reason="no second Python with scikit-image in this image")
+def test_patch_moments_equal_scikit_image(oracle, euroc_left, tmp_path):
+    """IC_Angle's circular 31 x 31 patch (row extents umax[|v|], src/ORBextractor.cc:74-101, :1010-1025): scikit-image's
+    corner_orientations with its own oFAST mask gives atan2(m01, m10) of the same patch in double precision; the
+    oracle's integer moments must give the same angle."""
+    import math
+    rng = np.random.default_rng(3)
+    img = np.ascontiguousarray(euroc_left)
+    h, w = img.shape
+    pts = np.stack([rng.integers(20, h - 20, 300), rng.integers(20, w - 20, 300)], axis=1)      # (row, col)
+    child = tmp_path / "child_orient.py"
+    child.write_text(ORIENT_CHILD)
+    a, b, c = tmp_path / "img.npy", tmp_path / "pts.npy", tmp_path / "ang.npy"
+    np.save(a, img)
+    np.save(b, pts)
+    subprocess.run([OTHER_PYTHON, str(child), str(a), str(b), str(c)], check=True, timeout=300,
+                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    theirs = np.load(c)
+    worst = 0.0
+    for (y, x), ang in zip(pts, theirs):
+        m01, m10 = oracle.ic_moments(img, int(x), int(y))
+        mine = math.atan2(m01, m10)
+        d = abs(mine - float(ang))
+        worst = max(worst, min(d, 2 * math.pi - d))
+    assert worst < 1e-9, worst

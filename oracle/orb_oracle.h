@@ -11,6 +11,11 @@
  * nor installed here.  This file therefore restates the published OpenCV 3.4.1
  * generic (non-IPP) algorithms at the reference's call sites; every OpenCV
  * semantic choice is in orb_oracle.c under a "OpenCV 3.4.1 semantics" banner.
+ * What stands in for the missing pin: double-precision bounds on resize, blur
+ * and fastAtan2 (tests/test_oracle_semantics.py) and comparisons with
+ * scikit-image / scipy where a second Python of the image has them
+ * (tests/test_oracle_skimage.py: FAST segment test, resize sampling rule,
+ * Gaussian, patch moments, rBRIEF pattern).
  *
  * Each function cites the reference file:line it follows.
  */

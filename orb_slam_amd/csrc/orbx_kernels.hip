@@ -1143,8 +1143,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     int* s_var = s_C + M;                                                               // 64
     short* s_cidx = reinterpret_cast<short*>(s_var + 64);                               // 2*M
     unsigned short* s_childpos = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);     // 4*M
-    unsigned short* s_newpos = s_childpos + 4 * M;                                      // M
-    unsigned short* s_order = s_newpos + M;                                             // M
+    unsigned short* s_order = s_childpos + 5 * M;                                       // M (M entries before it are unused)
     unsigned short* s_cand = s_order + M;                                               // M
     unsigned char* s_fl = reinterpret_cast<unsigned char*>(s_cand + M);                 // M
     int* s_tmp = s_var + 16;     // scan scratch, one int per wavefront (two for the paired scan)
@@ -1300,7 +1299,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     __syncthreads();
     int size = lds_excl_scan<NT>(s_B, nIni, s_tmp);
     int cur = 0;
-    for (int r = tid; r < nIni; r += NT)
+    for (int r = tid; r < nIni; r += NT) {
+        s_childpos[4 * r] = (unsigned short)s_B[r];      // root counter -> list position, applied by the first key pass
         if (s_A[r] > 0) {
             int pos = s_B[r];
             QNode q;
@@ -1312,8 +1312,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             s_cnt[pos] = s_A[r];
             s_cidx[pos] = -1;
         }
-    __syncthreads();
-    FOR_KEYS({ nd = (uint32_t)s_B[nd]; })
+    }
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
     __syncthreads();
 
@@ -1342,8 +1341,11 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         //    so it runs before the keys are visited and the two passes below share one barrier)
         int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
         // c. child occupancy (DivideNode :431-476)
+        //    A key first moves to its node's position in this step's list: s_childpos still holds the previous step's
+        //    map (child position per quadrant of a split node, the new position in all four entries of any other node).
         FOR_KEYS({
-            int p = (int)(nd & kNodeMask);
+            int p = (int)s_childpos[4 * (int)(nd & kNodeMask) + (int)(nd >> NB)];
+            nd = (uint32_t)p;
             if (s_fl[p]) {
                 QNode q = rc[p];
                 int x = (int)(xy & 0xffff), y = (int)(xy >> 16);
@@ -1453,17 +1455,12 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         for (int p = tid; p < size; p += NT)
             if (!s_fl[p]) {
                 int pos = totalch + s_C[p];
-                s_newpos[p] = (unsigned short)pos;
+                s_childpos[4 * p] = s_childpos[4 * p + 1] = s_childpos[4 * p + 2] = s_childpos[4 * p + 3] = (unsigned short)pos;
                 rn[pos] = rc[p];
                 cn_nxt[pos] = cc_cur[p];
                 ci_nxt[pos] = -1;
             }
-        __syncthreads();
-        // f. move the keys
-        FOR_KEYS({
-            int p = (int)(nd & kNodeMask);
-            nd = s_fl[p] ? s_childpos[4 * p + (int)(nd >> NB)] : s_newpos[p];
-        })
+        // f. the keys move at the start of the next step's pass over them (or of the final one)
         // g. loop control (:618-622, :683-684)
         if (tid == 0) {
             s_var[4] = newsize;
@@ -1480,8 +1477,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     for (int p = tid; p < size; p += NT) s_best[p] = 0ull;
     __syncthreads();
     FOR_KEYS({
+        nd = (uint32_t)s_childpos[4 * (int)(nd & kNodeMask) + (int)(nd >> NB)];
         unsigned long long v = ((unsigned long long)resp << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-        atomicMax(&s_best[nd & kNodeMask], v);
+        atomicMax(&s_best[nd], v);
     })
 #undef FOR_KEYS
     __syncthreads();

@@ -1499,7 +1499,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 // Two shapes of the same body.  256 threads x 10 register keys (91 VGPRs, 5 wavefronts per SIMD) is
 // the throughput shape for batches.  1024 threads x 3 register keys shortens the per-key passes of
 // a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
-__global__ __launch_bounds__(256) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs, 11>(QUADTREE_ARGS); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_quadtree(QUADTREE_PARAMS) { quadtree_body<256, kKeyRegs, 11>(QUADTREE_ARGS); }
 __global__ __launch_bounds__(1024) void k_quadtree_wide(QUADTREE_PARAMS) { quadtree_body<1024, kKeyRegsWide, 11, 8>(QUADTREE_ARGS); }
 // 512 threads x 5 register keys: between the two, for batches that fill the device only once
 __global__ __launch_bounds__(512) void k_quadtree_mid(QUADTREE_PARAMS) { quadtree_body<512, 5, 11>(QUADTREE_ARGS); }

@@ -149,7 +149,7 @@ __device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint
 // rows [r0, r1) of destination dword column dwc of level L, from level P of the same frame
 __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, const LevelGeom& P,
                                             const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
-                                            int dwc, int r0, int r1)
+                                            int dwc, int r0, int r1, int mirror)
 {
     const XTab4 x = xtab[L.xtab4_off + dwc];
     // The 8 source bytes of this lane start at an arbitrary byte; a misaligned vector load is split
@@ -214,6 +214,14 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
                 hp[j] = h1[j];
             }
             *reinterpret_cast<uint32_t*>(dst + (size_t)((uint32_t)(rr[k] * (int)L.pitch) + doff)) = o;
+            if (mirror) {
+                // REFLECT_101 rows: image row d is also border row -d (d = 1 .. kPadY) and row 2 (h - 1) - d below the image
+                const int d = rr[k] - kPadY;
+                if (d >= 1 && d <= kPadY)
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)((uint32_t)((kPadY - d) * (int)L.pitch) + doff)) = o;
+                if (d >= L.h - 1 - kPadY && d <= L.h - 2)
+                    *reinterpret_cast<uint32_t*>(dst + (size_t)((uint32_t)((kPadY + 2 * (L.h - 1) - d) * (int)L.pitch) + doff)) = o;
+            }
         }
         prev_off = y[3].off1;
     }
@@ -221,18 +229,21 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
 
 __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr, FrameGeom g, int level,
                                                       const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
-                                                      int rows_per_band, int ncb)
+                                                      int rows_per_band, int ncb, int mirror)
 {
     const LevelGeom& L = g.lv[level];
     const int lane = threadIdx.x & 63;
     const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int rb = item / ncb, cb = item - rb * ncb;
     const int dwc = cb * 64 + lane;
+    // With `mirror` the bands cover the image rows only and every row near the top / bottom edge is stored a second time
+    // as the border row it reflects into (the border rows are a fifth of a small level: not computed twice).
+    const int row_lo = mirror ? kPadY : 0, row_hi = mirror ? kPadY + L.h : L.rows;
     // the band is the same for the whole wavefront: keep its row numbers in scalar registers so
     // that the row table comes in through scalar loads instead of one vector load per lane
-    const int r0 = __builtin_amdgcn_readfirstlane(rb * rows_per_band), r1 = min(r0 + rows_per_band, L.rows);
-    if (dwc * 4 >= L.pitch || r0 >= L.rows) return;
-    resize_band(pyr + (size_t)blockIdx.y * g.pyr_frame_bytes, L, g.lv[level - 1], xtab, ytab, dwc, r0, r1);
+    const int r0 = __builtin_amdgcn_readfirstlane(row_lo + rb * rows_per_band), r1 = min(r0 + rows_per_band, row_hi);
+    if (dwc * 4 >= L.pitch || r0 >= row_hi) return;
+    resize_band(pyr + (size_t)blockIdx.y * g.pyr_frame_bytes, L, g.lv[level - 1], xtab, ytab, dwc, r0, r1, mirror);
 }
 
 // ---------------------------------------------------------------------------
@@ -1803,9 +1814,15 @@ void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab
     const LevelGeom& L = g.lv[level];
     const int rows_per_band = 8;     // measured: 8 beats 4, 16 and 32 (short wavefronts hide the load latency, long ones reuse more rows)
     const int ncb = (L.pitch / 4 + 63) / 64;
-    const int nrb = (L.rows + rows_per_band - 1) / rows_per_band;
+    // Levels tall enough for a single reflection (all but the last levels of tiny images) compute image rows only, in
+    // batches: a lone frame is bound by the latency of its seven dependent launches, where fewer, longer wavefronts
+    // cost more than the border rows save (36 against 32 us).
+    static const bool no_mirror = getenv("ORBX_RESIZE_NO_MIRROR") != nullptr;
+    const int mirror = (!no_mirror && nframes >= 8 && L.h >= 2 * kPadY + 2) ? 1 : 0;
+    const int nrows = mirror ? L.h : L.rows;
+    const int nrb = (nrows + rows_per_band - 1) / rows_per_band;
     dim3 grid((ncb * nrb + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb);
+    hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb, mirror);
 }
 
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)

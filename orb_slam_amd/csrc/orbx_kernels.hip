@@ -1812,7 +1812,8 @@ void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab
                          int nframes, hipStream_t s)
 {
     const LevelGeom& L = g.lv[level];
-    const int rows_per_band = 8;     // measured: 8 beats 4, 16 and 32 (short wavefronts hide the load latency, long ones reuse more rows)
+    static const int env_rows = getenv("ORBX_RESIZE_ROWS") ? atoi(getenv("ORBX_RESIZE_ROWS")) : 0;
+    const int rows_per_band = env_rows > 0 ? env_rows : 8;     // measured: 8 beats 4, 16 and 32 (short wavefronts hide the load latency, long ones reuse more rows)
     const int ncb = (L.pitch / 4 + 63) / 64;
     // Levels tall enough for a single reflection (all but the last levels of tiny images) compute image rows only, in
     // batches: a lone frame is bound by the latency of its seven dependent launches, where fewer, longer wavefronts

@@ -471,3 +471,22 @@ def test_randomised_soak():
                        capture_output=True, text=True, timeout=110)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "0 mismatches" in r.stdout
+
+
+@pytest.mark.parametrize("w,h,nlevels,scale", [(641, 481, 8, 1.2), (333, 207, 8, 1.2), (1241, 376, 8, 1.2), (500, 300, 5, 1.5),
+                                                (203, 122, 8, 1.3)])
+def test_batch_pyramid_borders_on_odd_sizes(w, h, nlevels, scale):
+    """In batches of 8 frames and more the resize computes image rows only and stores the rows near the top / bottom edge a
+    second time as the REFLECT_101 border rows (levels lower than 40 rows keep computing their border rows): every plane
+    of such a batch, border included, against the oracle, for sizes whose levels fall on both sides of that limit."""
+    from orb_slam_amd import ORBextractor
+    from oracle_lib import Oracle
+    ex = ORBextractor(600, scale, nlevels, 20, 7)
+    o = Oracle(600, scale, nlevels, 20, 7)
+    imgs = synthetic_batch(9, w, h, seed0=5100 + w)
+    res = ex.extract_batch(imgs)
+    for i in (0, 8):
+        kps_o, desc_o = _compare_frame(ex, o, imgs[i], frame=i, check_stages=True)
+        _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+        assert np.array_equal(res[i][1], desc_o)
+    ex.close()

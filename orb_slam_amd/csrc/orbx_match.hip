@@ -455,7 +455,9 @@ struct StereoArgs {
     const int32_t* row_start;       // per pair nrows + 1 offsets into sorted: right keypoints ordered by clamp(floor(y))
     const int32_t* sorted;          // per pair `stride` right keypoint indices
     int rband;                      // a band never reaches further than this many rows from floor(y)
-    int classic;                    // Frame::ComputeStereoMatches: row test of :1031-1033, no disparity here
+    int classic;                    // Frame::ComputeStereoMatches: row test of :1031-1033, then the SAD refinement
+    int32_t* sad;                   // classic: accepted best SAD per left keypoint of a pair (`sad_stride` ints per pair), -1 = none
+    int sad_stride;
     int init_outputs;               // u_right = depth = listed = -1 for every left keypoint first
     int median_cut;
 };
@@ -513,8 +515,90 @@ __global__ __launch_bounds__(256) void k_stereo_rows(const orbx_keypoint* __rest
     }
 }
 
-__global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc)
+// Classic stereo refinement of one left keypoint, Frame::ComputeStereoMatches src/Frame.cc:1070-1155, on one
+// wavefront: an 11x11 SAD window (each patch minus its centre pixel) slides +-5 px over the right pyramid
+// level kpL.octave; work item (row dy, shift incR) sums |a-b| over the 11 columns, 11 lanes then add the rows
+// (exact integers); parabola sub-pixel fit and disparity gating.  Returns the best SAD of an accepted match
+// (depth / u_right written by lane 0), -1 otherwise.  `part`: 128 ints of LDS owned by this wavefront.
+struct SadPlanes {
+    const uint8_t *pyrL, *pyrR;     // pyramids of the left and right extractor contexts (frame 0 of the launch)
+    ScaleTab inv_sc;
+};
+__device__ __forceinline__ int sad_refine(const orbx_keypoint& kpL, float uR0, const uint8_t* __restrict__ pyrL,
+                                          const uint8_t* __restrict__ pyrR, const FrameGeom& g, const ScaleTab& sc,
+                                          const ScaleTab& inv_sc, float mbf, float mb, float* u_right, float* depth,
+                                          int* part, int lane)
 {
+    const int lvl = min(max(kpL.octave, 0), g.nlevels - 1);
+    const LevelGeom& L = g.lv[lvl];
+    const float minD = 0.0f, maxD = __fdiv_rn(mbf, mb);
+    const float sf = inv_sc.v[lvl];
+    const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
+    const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
+    const float endu = __fadd_rn(scaleduR0, 11.0f);
+    bool ok = !(scaleduR0 < 0.0f || endu >= (float)L.w);
+    const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
+    // keep every access inside the stored plane even for keypoints the extractor would never produce
+    ok = ok && cy >= 5 - kPadY && cy < L.h + kPadY - 5 && cxL >= 5 - kPadX && cxL < L.w + kPadX - 5 &&
+         cxR0 >= 10 - kPadX && cxR0 < L.w + kPadX - 10;
+    if (!ok) return -1;                                 // wave-uniform
+    const uint8_t* imL = pyrL + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxL;
+    const uint8_t* imR = pyrR + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxR0;
+    const int cL = imL[0];
+    for (int it = lane; it < 121; it += 64) {
+        const int dy = it / 11 - 5, inc = it % 11 - 5;
+        const int cR = imR[inc];
+        const uint8_t* pl = imL + dy * L.pitch;
+        const uint8_t* pr = imR + dy * L.pitch + inc;
+        int acc = 0;
+#pragma unroll
+        for (int dx = -5; dx <= 5; dx++) acc += abs(((int)pl[dx] - cL) - ((int)pr[dx] - cR));
+        part[it] = acc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    int dist = 0x7fffffff;
+    if (lane < 11) {
+        dist = 0;
+        for (int r = 0; r < 11; r++) dist += part[r * 11 + lane];
+    }
+    // first minimum over the 11 shifts (strict '<' in the reference: lowest incR wins ties)
+    const int key = lane < 11 ? ((dist << 4) | lane) : 0x7fffffff;
+    int kmin = key;
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, __shfl_xor(kmin, d, 16));
+    kmin = __builtin_amdgcn_readfirstlane(kmin);
+    const int bestSlot = kmin & 15, bestSad = kmin >> 4;
+    const float d1 = (float)__shfl(dist, max(bestSlot - 1, 0), 64);
+    const float d2 = (float)__shfl(dist, bestSlot, 64);
+    const float d3 = (float)__shfl(dist, min(bestSlot + 1, 10), 64);
+    int accepted = -1;
+    if (bestSlot != 0 && bestSlot != 10) {
+        const float deltaR = __fdiv_rn(__fsub_rn(d1, d3), __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
+        if (!(deltaR < -1.0f || deltaR > 1.0f)) {
+            float bestuR = __fmul_rn(sc.v[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)(bestSlot - 5)), deltaR));
+            float disparity = __fsub_rn(kpL.x, bestuR);
+            if (disparity >= minD && disparity < maxD) {
+                if (disparity <= 0) {
+                    disparity = 0.01f;
+                    bestuR = (float)((double)kpL.x - 0.01);
+                }
+                if (lane == 0) {
+                    *depth = __fdiv_rn(mbf, disparity);
+                    *u_right = bestuR;
+                }
+                accepted = bestSad;
+            }
+        }
+    }
+    return accepted;
+}
+
+template <bool CLASSIC>
+__global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc, FrameGeom g, SadPlanes sp)
+{
+    __shared__ int s_part[CLASSIC ? 4 : 1][CLASSIC ? 128 : 1];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
     const int iL = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int nl = min(a.nl[b], a.stride);
@@ -566,18 +650,27 @@ __global__ __launch_bounds__(256) void k_stereo_scan(StereoArgs a, ScaleTab sc)
     }
     any = __ballot(any) != 0ull;
     key = wave_min_u32(key);
+    const bool found = (key >> 22) < 100u;          // bestDist starts at TH_HIGH, strict '<'
+    const int bdist = found ? (int)(key >> 22) : 100;
+    const int bidx = found ? (int)(key & 0x3FFFFFu) : 0;
+    if (CLASSIC) {
+        // the refinement of this keypoint follows on the same wavefront (src/Frame.cc:1070: bestDist < thOrbDist)
+        int sad = -1;
+        if (any && bdist < a.th_orb_dist)
+            sad = sad_refine(k, a.kr[(size_t)b * a.stride + bidx].x, sp.pyrL + (size_t)b * g.pyr_frame_bytes,
+                             sp.pyrR + (size_t)b * g.pyr_frame_bytes, g, sc, sp.inv_sc, a.mbf, a.mb, a.u_right + o, a.depth + o,
+                             s_part[threadIdx.x >> 6], lane);
+        if (lane == 0) a.sad[(size_t)b * a.sad_stride + iL] = sad;
+    }
     if (lane != 0) return;
     if (!any) {                                     // left before the scan: 'continue' / 'return false'
         a.best_idx[o] = -1;
         a.best_dist[o] = 100;
         return;
     }
-    const bool found = (key >> 22) < 100u;          // bestDist starts at TH_HIGH, strict '<'
-    const int bdist = found ? (int)(key >> 22) : 100;
-    const int bidx = found ? (int)(key & 0x3FFFFFu) : 0;
     a.best_idx[o] = bidx;
     a.best_dist[o] = bdist;
-    if (!a.classic && bdist < a.th_orb_dist) {
+    if (!CLASSIC && bdist < a.th_orb_dist) {
         float bestuR = a.kr[(size_t)b * a.stride + bidx].x;
         float disparity = __fsub_rn(uL, bestuR);
         if (disparity >= minD && disparity < maxD) {
@@ -643,122 +736,38 @@ __global__ __launch_bounds__(256) void k_stereo_finish(StereoArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// Classic stereo refinement, Frame::ComputeStereoMatches src/Frame.cc:1070-1172:
-// for every left keypoint whose Hamming match is below 75, an 11x11 SAD window
-// (each patch minus its centre pixel) slides +-5 px over the right pyramid
-// level kpL.octave; parabola sub-pixel fit, disparity gating, then the cut at
-// 2.1 x the median SAD.  One workgroup per stereo pair; one wavefront per
-// accepted keypoint at a time: work item (row dy, shift incR) sums |a-b| over the
-// 11 columns, 11 lanes then add the rows.  All sums are exact integers.
-// The pair's lists (keypoints to refine, accepted SADs and their keypoints) live in `lists`,
-// 3 * stride ints per pair of device memory, so the number of keypoints is not limited; the median
-// (element nacc / 2 in ascending order, :1159-1160) is found by two 256-bin histograms (an SAD is below 2^16).
+// Tail of Frame::ComputeStereoMatches, src/Frame.cc:1157-1172: the cut at 2.1 x the median SAD of the accepted
+// matches.  One workgroup per stereo pair over the per-keypoint SADs the scan launch left (-1 = no accepted
+// match).  The median is element nacc / 2 of the SADs in ascending order (:1159-1160), found by two 256-bin
+// histograms (an SAD is below 2^16); the number of keypoints is not limited.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restrict__ kl, const int32_t* __restrict__ nl_arr,
-                                                    const orbx_keypoint* __restrict__ kr, int stride,
-                                                    const uint8_t* __restrict__ pyrL, const uint8_t* __restrict__ pyrR,
-                                                    FrameGeom g, ScaleTab sc, ScaleTab inv_sc, float mbf, float mb,
-                                                    const int32_t* __restrict__ best_idx, const int32_t* __restrict__ best_dist,
-                                                    float* __restrict__ u_right, float* __restrict__ depth,
-                                                    int32_t* __restrict__ nmatched, int32_t* __restrict__ lists)
+__global__ __launch_bounds__(256) void k_stereo_sad_finish(const int32_t* __restrict__ nl_arr, int stride,
+                                                           const int32_t* __restrict__ sad_all, int sad_stride,
+                                                           float* __restrict__ u_right, float* __restrict__ depth,
+                                                           int32_t* __restrict__ nmatched)
 {
     __shared__ int s_hist[256];
-    __shared__ int s_part[4][128];
-    __shared__ int s_nlist, s_nacc, s_median, s_bin, s_rank;
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ int s_nacc, s_median, s_bin, s_rank;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int nl = min(nl_arr[b], stride);
-    int32_t* s_list = lists + (size_t)b * 3 * stride;       // left keypoints with a Hamming match < 75
-    int32_t* s_sad = s_list + stride;                       // accepted: best SAD
-    int32_t* s_acc = s_sad + stride;                        // accepted: left index
-    kl += (size_t)b * stride; kr += (size_t)b * stride;
-    best_idx += (size_t)b * stride; best_dist += (size_t)b * stride;
+    const int32_t* sad = sad_all + (size_t)b * sad_stride;
     u_right += (size_t)b * stride; depth += (size_t)b * stride;
-    pyrL += (size_t)b * g.pyr_frame_bytes; pyrR += (size_t)b * g.pyr_frame_bytes;
-    if (tid == 0) { s_nlist = 0; s_nacc = 0; }
+    if (tid == 0) s_nacc = 0;
     __syncthreads();
-    for (int iL = tid; iL < nl; iL += 256)
-        if (best_idx[iL] >= 0 && best_dist[iL] < 75) s_list[atomicAdd(&s_nlist, 1)] = iL;
+    int mine = 0;
+    for (int i = tid; i < nl; i += 256) mine += sad[i] >= 0;
+    if (mine) atomicAdd(&s_nacc, mine);
     __syncthreads();
-    const int nlist = s_nlist;
-    const float minD = 0.0f, maxD = __fdiv_rn(mbf, mb);
-    for (int e = wave; e < nlist; e += 4) {
-        const int iL = s_list[e];
-        const orbx_keypoint kpL = kl[iL];
-        const int lvl = min(max(kpL.octave, 0), g.nlevels - 1);
-        const LevelGeom& L = g.lv[lvl];
-        const float uR0 = kr[best_idx[iL]].x;
-        const float sf = inv_sc.v[lvl];
-        const float scaleduL = roundf(__fmul_rn(kpL.x, sf)), scaledvL = roundf(__fmul_rn(kpL.y, sf));
-        const float scaleduR0 = roundf(__fmul_rn(uR0, sf));
-        const float endu = __fadd_rn(scaleduR0, 11.0f);
-        bool ok = !(scaleduR0 < 0.0f || endu >= (float)L.w);
-        const int cy = (int)scaledvL, cxL = (int)scaleduL, cxR0 = (int)scaleduR0;
-        // keep every access inside the stored plane even for keypoints the extractor would never produce
-        ok = ok && cy >= 5 - kPadY && cy < L.h + kPadY - 5 && cxL >= 5 - kPadX && cxL < L.w + kPadX - 5 &&
-             cxR0 >= 10 - kPadX && cxR0 < L.w + kPadX - 10;
-        if (ok) {
-            const uint8_t* imL = pyrL + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxL;
-            const uint8_t* imR = pyrR + L.plane_off + (size_t)(kPadY + cy) * L.pitch + kPadX + cxR0;
-            const int cL = imL[0];
-            for (int it = lane; it < 121; it += 64) {
-                const int dy = it / 11 - 5, inc = it % 11 - 5;
-                const int cR = imR[inc];
-                const uint8_t* pl = imL + dy * L.pitch;
-                const uint8_t* pr = imR + dy * L.pitch + inc;
-                int acc = 0;
-#pragma unroll
-                for (int dx = -5; dx <= 5; dx++) acc += abs(((int)pl[dx] - cL) - ((int)pr[dx] - cR));
-                s_part[wave][it] = acc;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        int dist = 0x7fffffff;
-        if (ok && lane < 11) {
-            dist = 0;
-            for (int r = 0; r < 11; r++) dist += s_part[wave][r * 11 + lane];
-        }
-        // first minimum over the 11 shifts (strict '<' in the reference: lowest incR wins ties)
-        int key = (lane < 11 && ok) ? ((dist << 4) | lane) : 0x7fffffff;
-        int kmin = key;
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) kmin = min(kmin, __shfl_xor(kmin, d, 16));
-        const int bestSlot = kmin & 15, bestSad = kmin >> 4;
-        const float d1 = (float)__shfl(dist, max(bestSlot - 1, 0), 64);
-        const float d2 = (float)__shfl(dist, bestSlot, 64);
-        const float d3 = (float)__shfl(dist, min(bestSlot + 1, 10), 64);
-        if (lane == 0 && ok && bestSlot != 0 && bestSlot != 10) {
-            const float deltaR = __fdiv_rn(__fsub_rn(d1, d3),
-                                           __fmul_rn(2.0f, __fsub_rn(__fadd_rn(d1, d3), __fmul_rn(2.0f, d2))));
-            if (!(deltaR < -1.0f || deltaR > 1.0f)) {
-                float bestuR = __fmul_rn(sc.v[lvl], __fadd_rn(__fadd_rn(scaleduR0, (float)(bestSlot - 5)), deltaR));
-                float disparity = __fsub_rn(kpL.x, bestuR);
-                if (disparity >= minD && disparity < maxD) {
-                    if (disparity <= 0) {
-                        disparity = 0.01f;
-                        bestuR = (float)((double)kpL.x - 0.01);
-                    }
-                    depth[iL] = __fdiv_rn(mbf, disparity);
-                    u_right[iL] = bestuR;
-                    const int slot = atomicAdd(&s_nacc, 1);
-                    s_sad[slot] = bestSad;
-                    s_acc[slot] = iL;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // median = SAD of element nacc/2 of the list sorted by (SAD, left index), :1159-1160: the bin of the high byte that
-    // holds that rank, then the low byte inside the bin
     const int nacc = s_nacc;
     if (tid == 0) { s_median = -1; s_bin = 0; s_rank = nacc / 2; }
     for (int pass = 0; pass < 2 && nacc > 0; pass++) {
         s_hist[tid] = 0;
         __syncthreads();
         const int bin = s_bin;
-        for (int i = tid; i < nacc; i += 256) {
-            const int di = min(s_sad[i], 0xffff);
+        for (int i = tid; i < nl; i += 256) {
+            const int v = sad[i];
+            if (v < 0) continue;
+            const int di = min(v, 0xffff);
             if (pass == 0) atomicAdd(&s_hist[di >> 8], 1);
             else if ((di >> 8) == bin) atomicAdd(&s_hist[di & 255], 1);
         }
@@ -778,12 +787,14 @@ __global__ __launch_bounds__(256) void k_stereo_sad(const orbx_keypoint* __restr
     int removed = 0;
     if (nacc > 0) {
         const float thDist = __fmul_rn(1.5f * 1.4f, (float)s_median);
-        for (int i = tid; i < nacc; i += 256)
-            if (!((float)s_sad[i] < thDist)) {
-                u_right[s_acc[i]] = -1.0f;
-                depth[s_acc[i]] = -1.0f;
+        for (int i = tid; i < nl; i += 256) {
+            const int v = sad[i];
+            if (v >= 0 && !((float)v < thDist)) {
+                u_right[i] = -1.0f;
+                depth[i] = -1.0f;
                 removed++;
             }
+        }
     }
     if (removed) atomicSub(&s_nacc, removed);
     __syncthreads();
@@ -815,10 +826,11 @@ void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t
     a.stride = L.stride; a.nrows = L.nrows; a.th_orb_dist = L.th_orb_dist;
     a.mbf = L.mbf; a.mb = L.mb; a.min_x = L.min_x;
     a.classic = 0; a.init_outputs = L.init_outputs; a.median_cut = L.median_cut;
+    a.sad = nullptr; a.sad_stride = 0;
     a.row_start = L.d_rows; a.sorted = L.d_rows + (size_t)L.nbatch * (L.nrows + 1); a.rband = stereo_rband(scale8);
     hipLaunchKernelGGL(k_stereo_rows, dim3(L.nbatch), dim3(256), (size_t)(2 * (L.nrows + 1)) * 4, s, L.d_kr, L.d_nr, L.stride,
                        L.nrows, L.d_rows, L.d_rows + (size_t)L.nbatch * (L.nrows + 1));
-    hipLaunchKernelGGL(k_stereo_scan, dim3((L.stride + 3) / 4, L.nbatch), dim3(256), 0, s, a, sc);
+    hipLaunchKernelGGL(k_stereo_scan<false>, dim3((L.stride + 3) / 4, L.nbatch), dim3(256), 0, s, a, sc, FrameGeom{}, SadPlanes{});
     hipLaunchKernelGGL(k_stereo_finish, dim3(L.nbatch), dim3(256), 0, s, a);
 }
 
@@ -840,13 +852,16 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
     a.stride = stride; a.nrows = nrows; a.th_orb_dist = 75;
     a.mbf = mbf; a.mb = mb; a.min_x = 0.0f;
     a.classic = 1; a.init_outputs = 1; a.median_cut = 0;
+    // the per-keypoint SADs take the first `stride` ints of each pair's share of the refinement scratch
+    a.sad = d_rows + stereo_rows_ints(nbatch, stride, nrows); a.sad_stride = 3 * stride;
     a.row_start = d_rows; a.sorted = d_rows + (size_t)nbatch * (nrows + 1); a.rband = stereo_rband(scale8);
+    SadPlanes sp;
+    sp.pyrL = pyrL; sp.pyrR = pyrR; sp.inv_sc = isc;
     hipLaunchKernelGGL(k_stereo_rows, dim3(nbatch), dim3(256), (size_t)(2 * (nrows + 1)) * 4, s, d_kr, d_nr, stride, nrows,
                        d_rows, d_rows + (size_t)nbatch * (nrows + 1));
-    hipLaunchKernelGGL(k_stereo_scan, dim3((stride + 3) / 4, nbatch), dim3(256), 0, s, a, sc);
-    hipLaunchKernelGGL(k_stereo_sad, dim3(nbatch), dim3(256), 0, s, d_kl, d_nl, d_kr, stride, pyrL, pyrR, g, sc, isc,
-                       mbf, mb, d_best_idx, d_best_dist, d_u_right, d_depth, d_nmatched,
-                       d_rows + stereo_rows_ints(nbatch, stride, nrows));
+    hipLaunchKernelGGL(k_stereo_scan<true>, dim3((stride + 3) / 4, nbatch), dim3(256), 0, s, a, sc, g, sp);
+    hipLaunchKernelGGL(k_stereo_sad_finish, dim3(nbatch), dim3(256), 0, s, d_nl, stride, a.sad, a.sad_stride, d_u_right,
+                       d_depth, d_nmatched);
 }
 
 // ---------------------------------------------------------------------------
@@ -968,30 +983,31 @@ __global__ __launch_bounds__(256) void k_grid_search(const orbx_keypoint* __rest
     const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
     const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
     int wr = LIST ? cand_off[qo] : 0;
+    // cells are numbered column by column (ix * 48 + iy), so the lists of the cells iy = nMinCellY .. nMaxCellY of one
+    // column are one contiguous run of cell_list, in the reference's visiting order
     if (!empty)
-        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
-            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
-                const int c = ix * kGridRows + iy;
-                for (int j = cell_start[c]; j < cell_start[c + 1]; j++) {
-                    const int idx = cell_list[j];
-                    const orbx_keypoint kp = kps[idx];
-                    if (checkLevels) {
-                        if (kp.octave < minLevel) continue;
-                        if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++) {
+            const int j1 = cell_start[ix * kGridRows + nMaxCellY + 1];
+            for (int j = cell_start[ix * kGridRows + nMinCellY]; j < j1; j++) {
+                const int idx = cell_list[j];
+                const orbx_keypoint kp = kps[idx];
+                if (checkLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                if (fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r) {
+                    if (LIST) cand_idx[wr++] = idx;
+                    if (has_desc) {
+                        const uint4* tp = reinterpret_cast<const uint4*>(desc + (size_t)idx * 8);
+                        const int d = hamming256(qd, tp[0], tp[1]);
+                        const uint32_t key = ((uint32_t)d << 22) | (uint32_t)min(count, 0x3FFFFF);
+                        if (key < best) { second = best; si = bi; best = key; bi = idx; }
+                        else if (key < second) { second = key; si = idx; }
                     }
-                    if (fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r) {
-                        if (LIST) cand_idx[wr++] = idx;
-                        if (has_desc) {
-                            const uint4* tp = reinterpret_cast<const uint4*>(desc + (size_t)idx * 8);
-                            const int d = hamming256(qd, tp[0], tp[1]);
-                            const uint32_t key = ((uint32_t)d << 22) | (uint32_t)min(count, 0x3FFFFF);
-                            if (key < best) { second = best; si = bi; best = key; bi = idx; }
-                            else if (key < second) { second = key; si = idx; }
-                        }
-                        count++;
-                    }
+                    count++;
                 }
             }
+        }
     if (ncand) ncand[qo] = count;
     if (has_desc) {
         const bool bok = (best >> 22) < 256u, sok = (second >> 22) < 256u;
@@ -1001,6 +1017,80 @@ __global__ __launch_bounds__(256) void k_grid_search(const orbx_keypoint* __rest
         if (best_lvl) best_lvl[qo] = bok ? kps[bi].octave : -1;
         if (second_lvl) second_lvl[qo] = sok ? kps[si].octave : -1;
     }
+}
+
+// The fused search (query descriptors given, no lists): 16 lanes per query, lane = cell column of the query's
+// window.  A candidate's place in the reference's visiting order is its position in cell_list (columns ascending,
+// then rows, then the cell's list), so key = distance << 22 | position orders candidates exactly like the scan of
+// src/ORBmatcher.cc:186-225 (first candidate wins ties), in any evaluation order: every lane scans its columns'
+// runs, then the 16 (best, second) pairs are merged.
+__global__ __launch_bounds__(256) void k_grid_search_coop(const orbx_keypoint* __restrict__ kps, const uint32_t* __restrict__ desc,
+                                                          const int* __restrict__ cell_start, const int* __restrict__ cell_list,
+                                                          int stride, GridQueryArgs a, float minX, float minY, float invW, float invH,
+                                                          int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                          int32_t* __restrict__ second_dist, int32_t* __restrict__ best_lvl,
+                                                          int32_t* __restrict__ second_lvl, int32_t* __restrict__ ncand)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+    const int nQ = a.nq ? min(a.nq[b], a.q_stride) : a.Q;
+    if (q >= nQ) return;                      // whole 16-lane groups leave together
+    kps += (size_t)b * stride;
+    desc += (size_t)b * stride * 8;
+    cell_start += (size_t)b * (kGridCells + 1);
+    cell_list += (size_t)b * stride;
+    const size_t qo = (size_t)b * a.q_stride + q;
+    const float x = a.qx[qo], y = a.qy[qo], r = a.qr[qo];
+    const int minLevel = a.qmin[qo], maxLevel = a.qmax[qo];
+    const int nMinCellX = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(x, minX), r), invW)));
+    const int nMaxCellX = min(kGridCols - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(x, minX), r), invW)));
+    const int nMinCellY = max(0, (int)floorf(__fmul_rn(__fsub_rn(__fsub_rn(y, minY), r), invH)));
+    const int nMaxCellY = min(kGridRows - 1, (int)ceilf(__fmul_rn(__fadd_rn(__fsub_rn(y, minY), r), invH)));
+    const bool empty = nMinCellX >= kGridCols || nMaxCellX < 0 || nMinCellY >= kGridRows || nMaxCellY < 0;
+    const bool checkLevels = (minLevel > 0) || (maxLevel >= 0);
+    uint32_t best = kKeyNone, second = kKeyNone;
+    int count = 0;
+    if (!empty && nMinCellX + sub <= nMaxCellX) {
+        uint32_t qd[8];
+        const uint4* qp = reinterpret_cast<const uint4*>(a.qdesc + qo * 8);
+        const uint4 u = qp[0], v = qp[1];
+        qd[0] = u.x; qd[1] = u.y; qd[2] = u.z; qd[3] = u.w;
+        qd[4] = v.x; qd[5] = v.y; qd[6] = v.z; qd[7] = v.w;
+        for (int ix = nMinCellX + sub; ix <= nMaxCellX; ix += 16) {
+            const int j1 = cell_start[ix * kGridRows + nMaxCellY + 1];
+            for (int j = cell_start[ix * kGridRows + nMinCellY]; j < j1; j++) {
+                const int idx = cell_list[j];
+                const orbx_keypoint kp = kps[idx];
+                if (checkLevels) {
+                    if (kp.octave < minLevel) continue;
+                    if (maxLevel >= 0 && kp.octave > maxLevel) continue;
+                }
+                if (fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r) {
+                    const uint4* tp = reinterpret_cast<const uint4*>(desc + (size_t)idx * 8);
+                    const int d = hamming256(qd, tp[0], tp[1]);
+                    push_key(best, second, ((uint32_t)d << 22) | (uint32_t)j);
+                    count++;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
+        const uint32_t ob = (uint32_t)__shfl_xor((int)best, d, 16), os = (uint32_t)__shfl_xor((int)second, d, 16);
+        count += __shfl_xor(count, d, 16);
+        const uint32_t nb = min(best, ob);
+        second = min(max(best, ob), min(second, os));
+        best = nb;
+    }
+    if (sub != 0) return;
+    if (ncand) ncand[qo] = count;
+    const bool bok = (best >> 22) < 256u, sok = (second >> 22) < 256u;
+    const int bi = bok ? cell_list[best & 0x3FFFFFu] : -1, si = sok ? cell_list[second & 0x3FFFFFu] : -1;
+    best_idx[qo] = bi;
+    best_dist[qo] = (int32_t)(best >> 22);
+    second_dist[qo] = (int32_t)(second >> 22);
+    if (best_lvl) best_lvl[qo] = bok ? kps[bi].octave : -1;
+    if (second_lvl) second_lvl[qo] = sok ? kps[si].octave : -1;
 }
 
 void launch_grid_build(const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch, float minX,
@@ -1020,6 +1110,12 @@ void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, cons
     if (q_stride <= 0) return;
     GridQueryArgs a{qx, qy, qr, qmin, qmax, qdesc, d_nq, Q, q_stride};
     dim3 grid((q_stride + 255) / 256, nbatch);
+    if (!cand_idx && qdesc) {
+        hipLaunchKernelGGL(k_grid_search_coop, dim3((q_stride + 15) / 16, nbatch), dim3(256), 0, s, d_kps, d_desc, d_cell_start,
+                           d_cell_list, stride, a, minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl,
+                           second_lvl, ncand);
+        return;
+    }
     if (cand_idx)
         hipLaunchKernelGGL(k_grid_search<true>, grid, dim3(256), 0, s, d_kps, d_desc, d_cell_start, d_cell_list, stride, a,
                            minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl, second_lvl, ncand, cand_off,

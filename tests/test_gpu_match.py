@@ -445,6 +445,114 @@ def test_stereo_ex_device_batched(ex, matcher, oracle):
         assert (listed[b, n:] == -1).all() and (ur[b, n:] == -1).all()
 
 
+def test_stereo_sad_device_batched():
+    """orbx_stereo_match_sad_device over several pairs resident on the device: extraction of the left and right
+    frames on two contexts, then Frame::ComputeStereoMatches per pair (one wavefront per left keypoint)."""
+    torch = pytest.importorskip("torch")
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    from oracle_lib import Oracle
+    dev = torch.device("cuda:0")
+    W, H, nb = 752, 480, 3
+    pairs = [synthetic_stereo_pair(W, H, 900 + i) for i in range(nb)]
+    pairs[2] = (pairs[2][0], np.full((H, W), 90, np.uint8))          # a right frame without keypoints
+    exl, exr = ORBextractor(1000, 1.2, 8, 20, 7), ORBextractor(1000, 1.2, 8, 20, 7)
+    stream = torch.cuda.current_stream().cuda_stream
+    exl.set_stream(stream)
+    exr.set_stream(stream)
+    cap = exl.max_keypoints(W, H)
+    side = []
+    for ex_, imgs in ((exl, [p[0] for p in pairs]), (exr, [p[1] for p in pairs])):
+        d_img = torch.from_numpy(np.stack(imgs)).to(dev)
+        d_k = torch.zeros((nb, cap, 7), dtype=torch.float32, device=dev)
+        d_d = torch.zeros((nb, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros((nb,), dtype=torch.int32, device=dev)
+        ex_.extract_batch_device(d_img, nb, W, H, W, W * H, d_k, d_d, cap, d_n)
+        side.append((d_k, d_d, d_n))
+    (kl, dl, nl), (kr, dr, nr) = side
+    d_bi = torch.full((nb, cap), -9, dtype=torch.int32, device=dev)
+    d_bd = torch.full((nb, cap), -9, dtype=torch.int32, device=dev)
+    d_ur = torch.full((nb, cap), -7.0, dtype=torch.float32, device=dev)
+    d_dp = torch.full((nb, cap), -7.0, dtype=torch.float32, device=dev)
+    d_nm = torch.full((nb,), -9, dtype=torch.int32, device=dev)
+    mbf, mb = 47.9, 0.11
+    for _ in range(2):            # a second call reuses the scratch of the first
+        ORBmatcher(exl).stereo_match_sad_device(exr, kl, dl, nl, kr, dr, nr, nb, cap, mbf, mb, d_bi, d_bd, d_ur, d_dp, d_nm)
+    torch.cuda.synchronize()
+    exl.set_stream(None)
+    exr.set_stream(None)
+    h_nl, h_nr = nl.cpu().numpy(), nr.cpu().numpy()
+    assert h_nr[2] == 0 and h_nl[2] > 900
+    h_kl = kl.cpu().numpy().view(np.uint8).reshape(nb, cap, 28).view(KP_DTYPE).reshape(nb, cap)
+    h_kr = kr.cpu().numpy().view(np.uint8).reshape(nb, cap, 28).view(KP_DTYPE).reshape(nb, cap)
+    h_dl, h_dr = dl.cpu().numpy(), dr.cpu().numpy()
+    bi, bd, ur, dp, nm = (t.cpu().numpy() for t in (d_bi, d_bd, d_ur, d_dp, d_nm))
+    for b in range(nb):
+        ol, orr = Oracle(1000, 1.2, 8, 20, 7), Oracle(1000, 1.2, 8, 20, 7)
+        k_l, _ = ol.extract(pairs[b][0])
+        k_r, _ = orr.extract(pairs[b][1])
+        n_l, n_r = int(h_nl[b]), int(h_nr[b])
+        assert np.array_equal(h_kl[b, :n_l], k_l) and np.array_equal(h_kr[b, :n_r], k_r)
+        oi, od, our, odp, onm = ol.stereo_classic(orr, h_kl[b, :n_l], h_dl[b, :n_l], h_kr[b, :n_r], h_dr[b, :n_r], mbf, mb)
+        assert np.array_equal(bi[b, :n_l], oi) and np.array_equal(bd[b, :n_l], od), b
+        assert np.array_equal(ur[b, :n_l], our) and np.array_equal(dp[b, :n_l], odp), b       # floats bit-identical
+        assert nm[b] == onm, b
+        if b < 2:
+            assert (our >= 0).sum() > 100
+    exl.close()
+    exr.close()
+
+
+def test_grid_search_device_batched(ex, matcher, oracle):
+    """orbx_grid_search_device over several frames with ragged keypoint and query counts (16 lanes per query):
+    windows wider than 16 cell columns, queries outside the grid, equal distances (the first candidate in the
+    reference's visiting order wins), a frame without queries and one without keypoints."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(33)
+    nb, stride, qs = 4, 1500, 900
+    n = np.array([1500, 1000, 0, 700], np.int32)
+    nq = np.array([900, 333, 50, 0], np.int32)
+    kps = np.zeros((nb, stride), KP_DTYPE)
+    desc = np.zeros((nb, stride, 32), np.uint8)
+    qx = np.zeros((nb, qs), np.float32); qy = np.zeros((nb, qs), np.float32); qr = np.ones((nb, qs), np.float32)
+    qmin = np.zeros((nb, qs), np.int32); qmax = np.zeros((nb, qs), np.int32)
+    qd = np.zeros((nb, qs, 32), np.uint8)
+    for b in range(nb):
+        kps[b]["x"] = rng.uniform(-5, 757, stride).astype(np.float32)
+        kps[b]["y"] = rng.uniform(-5, 485, stride).astype(np.float32)
+        kps[b]["octave"] = rng.integers(0, 8, stride)
+        desc[b] = random_descriptors(stride, 50 + b)
+        desc[b, 1::2] = desc[b, 0::2]                       # pairs of equal descriptors: ties between candidates
+        if n[b] == 0:
+            continue
+        x_, y_, r_, mn_, mx_, pick = _grid_queries(rng, kps[b, :n[b]], qs)
+        r_[::7] = rng.uniform(100, 260, len(r_[::7])).astype(np.float32)      # windows of 17 .. 45 cell columns
+        qx[b], qy[b], qr[b], qmin[b], qmax[b] = x_, y_, r_, mn_, mx_
+        qd[b] = desc[b][pick]
+    min_x, min_y = 0.0, 0.0
+    inv_w, inv_h = float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8) if a.dtype == KP_DTYPE else a).to(dev)
+    outs = [torch.full((nb, qs), -9, dtype=torch.int32, device=dev) for _ in range(6)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    matcher.grid_search_device(t(kps), t(desc), t(n), 0, stride, nb, min_x, min_y, inv_w, inv_h, t(qx), t(qy), t(qr),
+                               t(qmin), t(qmax), t(qd), t(nq), qs, qs, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    got = [o.cpu().numpy() for o in outs]
+    wide = 0
+    for b in range(nb):
+        k_, Q = kps[b, :n[b]], int(nq[b])
+        off_o, idx_o = oracle.features_in_area(k_, min_x, min_y, inv_w, inv_h, qx[b, :Q], qy[b, :Q], qr[b, :Q],
+                                               qmin[b, :Q], qmax[b, :Q])
+        ref = oracle.match_windowed(qd[b, :Q], desc[b, :n[b]], off_o, idx_o, k_["octave"])
+        for g_, r_, name in zip(got[:5], ref, ["best_idx", "best_dist", "second_dist", "best_lvl", "second_lvl"]):
+            assert np.array_equal(g_[b, :Q], r_), (b, name)
+        assert np.array_equal(got[5][b, :Q], np.diff(off_o)), b
+        assert (got[0][b, Q:] == -9).all()
+        wide += int((np.diff(off_o) > 100).sum())
+    assert wide > 50
+
+
 def test_cpp_delayed_stereo_class(ex, oracle, tmp_path):
     """orbx::DelayedStereo (include/orbx_host.hpp), the C++ form a Frame of the reference would hold, through
     the same online / one-point / offline sequence as the oracle's Frame state."""

@@ -127,7 +127,45 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(frames, nfeat):
+def cpu_frame_steps(sample):
+    """The oracle's single-thread time for the per-frame steps that follow extraction (undistortion, grid
+    candidate search, row-band stereo search, classic stereo search with SAD refinement) on one stereo pair
+    of the GPU leg: milliseconds per frame / pair."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import KP_DTYPE, Oracle
+    from orb_slam_amd.synth import synthetic_stereo_pair
+    kp = lambda a: np.ascontiguousarray(a).view(KP_DTYPE).reshape(-1)      # noqa: E731
+    kl, kr, dl, dr, q = kp(sample["kl"]), kp(sample["kr"]), sample["dl"], sample["dr"], sample["q"]
+    K, D, R, P = sample["cam"]
+    mbf, mb = sample["mbf"], sample["mb"]
+    ol = Oracle(1000, 1.2, 8, 20, 7, native=True, trig="libm")
+    orr = Oracle(1000, 1.2, 8, 20, 7, native=True, trig="libm")
+    left, right = synthetic_stereo_pair(752, 480, sample["seed"])
+    ol.extract(left)                 # the classic search reads both pyramids
+    orr.extract(right)
+    sf = ol.tables()["scale"]
+    xy = np.stack([kl["x"], kl["y"]], axis=1)
+
+    def grid():
+        off, idx = ol.features_in_area(kl, *sample["grid"], q["qx"], q["qy"], q["qr"], q["qmin"], q["qmax"])
+        ol.match_windowed(q["qd"], dl, off, idx, kl["octave"])
+    steps = {"undistort": lambda: ol.undistort_points(xy, K, D, R, P),
+             "grid_search": grid,
+             "stereo_rowband": lambda: ol.stereo_frame(kl, dl, kr, dr, sf, 480, mbf, mb, 0.0).ComputeStereoMatches_Undistorted(False),
+             "stereo_sad": lambda: ol.stereo_classic(orr, kl, dl, kr, dr, mbf, mb)}
+    out = {}
+    for name, fn in steps.items():
+        fn()
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 0.3:
+            fn()
+            n += 1
+        out[name] = round((time.perf_counter() - t0) / n * 1e3, 4)
+    return out
+
+
+def cpu_baseline(frames, nfeat, frame_sample=None):
     """The oracle (literal restatement of the reference's CPU path, built with the reference's
     -O3 -march=native) on a bounded sample of the same frames: one frame per thread on every core
     this job may use, for a fixed wall-clock time, then the same for 1000 x 1000 brute-force matching."""
@@ -184,7 +222,11 @@ def cpu_baseline(frames, nfeat):
     for t in threads:
         t.join()
     mwall = time.perf_counter() - t0
-    return {"value": round(multi, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
+    frame_steps = None
+    if frame_sample is not None:
+        frame_steps = {"ms_per_frame_single_thread": cpu_frame_steps(frame_sample), "cores": 1,
+                       "sample": "the first stereo pair of legs.frame_steps, 0.3 s per step"}
+    return {"frame_steps": frame_steps, "value": round(multi, 2), "unit": "frames/s", "cores": ncores, "kind": "port",
             "sample": "%d of the batch's frames, one frame per thread on %d threads for %.1f s (the job's CPU share; the node "
                       "shows %d logical CPUs); single thread: %.2f frames/s over %d frames"
                       % (sum(done), ncores, wall, os.cpu_count() or 0, single, n1),
@@ -487,6 +529,7 @@ def main():
         out["invariant"] = "frames 0 and %d of the timed batch are byte-identical to single-frame calls" % (len(wl.host) - 1)
 
     extras = not args.no_extras and world == 1 and args.config == "euroc"
+    frame_sample = None
     # ---- Hamming matching alone: every rank searches its own queries against its replica of the train set;
     #      the whole-job rate is the sum over the ranks ----
     if not args.no_extras and args.config == "euroc":
@@ -544,6 +587,17 @@ def main():
             w2.close()
             del w2
             torch.cuda.empty_cache()
+        # the per-frame steps that follow extraction in ORB_SLAM2::Frame, on 128 resident stereo pairs
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from frame_bench import measure as measure_frame_steps
+        fs_ms, fs_facts, frame_sample = measure_frame_steps(128, 20, dev, stream)
+        legs["frame_steps"] = {
+            "pairs": 128, "ms_per_call": {k: round(v, 4) for k, v in fs_ms.items()},
+            "frames_per_s": {k: round(128 / v * 1e3, 1) for k, v in fs_ms.items()},
+            "what": "orbx_undistort_keypoints_device (5 coefficients + rectification), orbx_grid_search_device (one query per "
+                    "left keypoint, radius 15 x its octave's scale), orbx_stereo_match_device, orbx_stereo_match_sad_device on "
+                    "the extraction output of 128 synthetic stereo pairs, resident",
+            **{k: round(v, 1) for k, v in fs_facts.items()}}
         # natural images: the reference's own EuRoC pair, 128 copies of each
         try:
             l_ = np.load(os.path.join(ROOT, "tests", "fixtures", "EuRoC_l.npy"))
@@ -609,7 +663,7 @@ def main():
         ex.set_stream(stream.cuda_stream)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(wl.host[:min(len(wl.host), 256)], wl.nfeat)
+        out["cpu_baseline"] = cpu_baseline(wl.host[:min(len(wl.host), 256)], wl.nfeat, frame_sample)
     elif rank == 0:
         out["cpu_baseline"] = None
 

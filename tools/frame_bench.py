@@ -17,6 +17,7 @@ from orb_slam_amd.frame import CameraModel, Frame  # noqa: E402
 from orb_slam_amd.synth import synthetic_stereo_pair  # noqa: E402
 
 W, H = 752, 480
+MBF, MB = 47.9, 0.11
 K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]], np.float64)
 D5 = np.array([-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0], np.float64)
 R = np.array([[0.999966347530033, -0.001422739138722922, 0.008079580483432283],
@@ -65,12 +66,9 @@ def frame_workload(pairs, dev, stream, seed0=4321):
     return exl, exr, cap, out, q, d_q
 
 
-def main():
-    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    dev = torch.device("cuda:0")
-    stream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(stream)
+def measure(pairs, reps, dev, stream):
+    """{step: ms per call over `pairs` stereo pairs} for the steps after extraction, the keypoint total, and a
+    host copy of the first pair's data (what a CPU timing of the same steps needs)"""
     exl, exr, cap, out, q, d_q = frame_workload(pairs, dev, stream)
     (kl, dl, nl), (kr, dr, nr) = out["l"], out["r"]
     m = ORBmatcher(exl)
@@ -83,16 +81,14 @@ def main():
     s_out = [i32(pairs, cap), i32(pairs, cap), f32(pairs, cap), f32(pairs, cap), i32(pairs)]
     c_out = [i32(pairs, cap), i32(pairs, cap), f32(pairs, cap), f32(pairs, cap), i32(pairs)]
     inv_w, inv_h = float(np.float32(64) / np.float32(W)), float(np.float32(48) / np.float32(H))
-    mbf, mb = 47.9, 0.11
     steps = {
         "undistort": lambda: fr.undistort_keypoints_device(kl, nl, 0, cap, pairs, cam, ku),
         "grid_search": lambda: m.grid_search_device(kl, dl, nl, 0, cap, pairs, 0.0, 0.0, inv_w, inv_h, d_q["qx"], d_q["qy"],
                                                     d_q["qr"], d_q["qmin"], d_q["qmax"], d_q["qd"], nl, cap, cap, *g_out),
-        "stereo_rowband": lambda: m.stereo_match_device(kl, dl, nl, kr, dr, nr, pairs, cap, H, mbf, mb, 0.0, *s_out),
-        "stereo_sad": lambda: m.stereo_match_sad_device(exr, kl, dl, nl, kr, dr, nr, pairs, cap, mbf, mb, *c_out),
+        "stereo_rowband": lambda: m.stereo_match_device(kl, dl, nl, kr, dr, nr, pairs, cap, H, MBF, MB, 0.0, *s_out),
+        "stereo_sad": lambda: m.stereo_match_sad_device(exr, kl, dl, nl, kr, dr, nr, pairs, cap, MBF, MB, *c_out),
     }
-    nkp = int(nl.sum().item())
-    print("%d pairs, %d left keypoints (%.0f per frame)" % (pairs, nkp, nkp / pairs))
+    ms = {}
     for name, fn in steps.items():
         for _ in range(3):
             fn()
@@ -103,13 +99,35 @@ def main():
             fn()
         t1.record()
         torch.cuda.synchronize()
-        ms = t0.elapsed_time(t1) / reps
-        print("%-15s %8.4f ms per %d pairs  %10.0f frames/s  %6.2f ns per keypoint" % (name, ms, pairs, pairs / ms * 1e3, ms * 1e6 / nkp))
-    print("grid candidates per query: %.1f   stereo matches per pair: row-band %.0f, SAD %.0f" % (
-        float(g_out[5].sum().item()) / nkp, float(s_out[4].float().mean().item()), float(c_out[4].float().mean().item())))
+        ms[name] = t0.elapsed_time(t1) / reps
+    nkp = int(nl.sum().item())
+    n0, m0 = int(nl[0].item()), int(nr[0].item())
+    facts = {"left_keypoints": nkp, "grid_candidates_per_query": float(g_out[5].sum().item()) / max(1, nkp),
+             "stereo_rowband_matches_per_pair": float((s_out[2] >= 0).sum().item()) / pairs,
+             "stereo_sad_matches_per_pair": float(c_out[4].float().mean().item())}
+    as_kp = lambda t, n: t[0, :n].cpu().numpy().view(np.uint8).reshape(n, 28)       # noqa: E731
+    sample = {"kl": as_kp(kl, n0), "dl": dl[0, :n0].cpu().numpy(), "kr": as_kp(kr, m0), "dr": dr[0, :m0].cpu().numpy(),
+              "q": {k_: v[0, :n0] for k_, v in q.items()}, "seed": 4321, "cam": (K, D5, R, P), "mbf": MBF, "mb": MB,
+              "grid": (0.0, 0.0, inv_w, inv_h)}
     for e in (exl, exr):
         e.set_stream(None)
         e.close()
+    return ms, facts, sample
+
+
+def main():
+    pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    dev = torch.device("cuda:0")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ms, facts, _ = measure(pairs, reps, dev, stream)
+    nkp = facts["left_keypoints"]
+    print("%d pairs, %d left keypoints (%.0f per frame)" % (pairs, nkp, nkp / pairs))
+    for name, v in ms.items():
+        print("%-15s %8.4f ms per %d pairs  %10.0f frames/s  %6.2f ns per keypoint" % (name, v, pairs, pairs / v * 1e3, v * 1e6 / nkp))
+    print("grid candidates per query: %.1f   stereo matches per pair: row-band %.0f, SAD %.0f" % (
+        facts["grid_candidates_per_query"], facts["stereo_rowband_matches_per_pair"], facts["stereo_sad_matches_per_pair"]))
 
 
 if __name__ == "__main__":

@@ -80,6 +80,8 @@ struct orbx_ctx {
     // per-batch working set
     int cap_frames = 0;
     DevBuf pyr, blur, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, qt_scratch;
+    DevBuf qt_counts;               // quadtree on node counts: per-launch scratch (leaves, sums and best keys)
+    CountLevels count_levels{};
 
     // staging for the host-buffer entry points
     DevBuf in, out_kps, out_desc, out_n;
@@ -182,6 +184,7 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
     // warm-up rows of horizontal sums: longer bands there (measured: 24 rows, 2 % off the fused launch)
     make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 24, c->blur_map_batch);
     make_fast_lds(c->g, c->fast_lds);
+    quadtree_count_levels(c->g, c->count_levels);
     c->gw = w;
     c->gh = h;
     c->cap_frames = 0;   // per-frame sizes changed
@@ -296,8 +299,18 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);
+    // levels with very many candidates (large frames) run their quadtree on node counts, if the scratch for it is moderate
+    const CountLevels* cl = nullptr;
+    if (c->count_levels.n > 0) {
+        const size_t need_bytes = (size_t)nframes * c->count_levels.n * c->count_levels.stride;
+        if (need_bytes <= ((size_t)1 << 30)) {
+            HIPCHECK(c, c->qt_counts.ensure(need_bytes));
+            cl = &c->count_levels;
+        }
+    }
     launch_quadtree(g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand,
-                    nframes, c->qt_scratch.as<unsigned char>() + F * kMaxLevels * quadtree_scratch_stride(g), s);
+                    nframes, c->qt_scratch.as<unsigned char>() + F * kMaxLevels * quadtree_scratch_stride(g), cl,
+                    c->qt_counts.as<unsigned char>(), s);
     t1(ST_QUADTREE, s);
     if (overlap) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     t0(ST_DESC, s);
@@ -505,7 +518,7 @@ void orbx_destroy(orbx_ctx* c)
     (void)hipSetDevice(c->device);
     (void)finish(c);
     DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
-                      &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->qt_scratch, &c->in, &c->out_kps,
+                      &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->qt_scratch, &c->qt_counts, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],
@@ -789,23 +802,31 @@ int orbx_debug_candidates(orbx_ctx* c, int frame, int level, int32_t* xyr, int c
     HIPCHECK(c, hipSetDevice(c->device));
     const FrameGeom& g = c->g;
     const LevelGeom& L = g.lv[level];
-    int cnt = 0;
-    HIPCHECK(c, d2h(c, &cnt, c->level_ncand.as<int>() + (size_t)frame * kMaxLevels + level, 4));
+    // the candidates of the level in the reference's append order (cells row by row, each cell's list in its own
+    // order), put together from the per-cell lists the FAST launch wrote
+    if (L.width == 0) { *n = 0; return ORBX_OK; }
+    const int ncell = L.nCols * L.nRows;
+    std::vector<int> counts(ncell);
+    HIPCHECK(c, d2h(c, counts.data(), c->cell_count.as<int>() + (size_t)frame * g.ncells + L.cell_base, (size_t)ncell * 4));
     HIPCHECK(c, finish(c));
-    *n = cnt;
+    long long cnt = 0;
+    for (int i = 0; i < ncell; i++) cnt += counts[i];
+    *n = (int)cnt;
     if (cnt > cap) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
     if (cnt == 0) return ORBX_OK;
     if (!xyr) return ORBX_ERR_INVALID;
-    std::vector<uint32_t> xy(cnt);
-    std::vector<uint8_t> rs(cnt);
-    const size_t base = (size_t)frame * g.keys_per_frame + L.key_base;
-    HIPCHECK(c, d2h(c, xy.data(), c->key_xy.as<uint32_t>() + base, (size_t)cnt * 4));
-    HIPCHECK(c, d2h(c, rs.data(), c->key_resp.as<uint8_t>() + base, (size_t)cnt));
+    std::vector<uint32_t> slots((size_t)ncell * L.cell_cap);
+    HIPCHECK(c, d2h(c, slots.data(), c->cell_cand.as<uint32_t>() + (size_t)frame * g.cand_per_frame + L.cand_base, slots.size() * 4));
     HIPCHECK(c, finish(c));
-    for (int i = 0; i < cnt; i++) {
-        xyr[3 * i] = (int32_t)(xy[i] & 0xffff);
-        xyr[3 * i + 1] = (int32_t)(xy[i] >> 16);
-        xyr[3 * i + 2] = rs[i];
+    int o = 0;
+    for (int cell = 0; cell < ncell; cell++) {
+        const int ci = cell / L.nCols, cj = cell - ci * L.nCols;
+        for (int j = 0; j < counts[cell]; j++, o++) {
+            const uint32_t u = slots[(size_t)cell * L.cell_cap + j];
+            xyr[3 * o] = cj * L.wCell + 3 + (int32_t)((u >> 8) & 0xff);
+            xyr[3 * o + 1] = ci * L.hCell + 3 + (int32_t)(u >> 16);
+            xyr[3 * o + 2] = (int32_t)(u & 0xff);
+        }
     }
     return ORBX_OK;
 }

@@ -1116,6 +1116,283 @@ __device__ __forceinline__ int ceil_half(int d)
     return (d + 1) >> 1;
 }
 
+// ---------------------------------------------------------------------------
+// DistributeOctTree on node counts alone, for levels with very many candidates (large frames).
+//
+// The rectangles of the tree do not depend on the data: a node is its root and the sequence of quadrants below it,
+// and DivideNode (:431-476) sends a key to the quadrant its coordinates select.  So a key's whole path is known in
+// advance, and the number of keys of any node is a sum over the leaves below it.  k_qt_bins (all keys of all
+// frames in parallel, no order) adds every key to its leaf at depth D and keeps the leaf's best key
+// (largest response, first in the reference's append order on ties); k_quadtree_counts builds the sums and
+// maxima of the shallower depths and then runs the same list steps as quadtree_body, reading a node's child
+// occupancy from the sums instead of passing over the keys (80 000 keys x 10 steps on one compute unit
+// otherwise).  A node is (depth, path), path = root * 4^depth + quadrant digits.  If a step has to split a node at
+// depth D the level is flagged and the ordinary kernel, launched next, serves it.
+// ---------------------------------------------------------------------------
+// entries of the depths below d (every depth padded to a multiple of 4 entries, so that a node's four children are one aligned load)
+__host__ __device__ inline int qt_depth_off(int nIni, int d)
+{
+    int o = 0;
+    for (int k = 0; k < d; k++) o += ((nIni << (2 * k)) + 3) & ~3;
+    return o;
+}
+// bytes of one (frame, level) slice: counts (int) of every depth, then best keys (64 bit) of every depth
+__host__ __device__ inline size_t qt_counts_bytes(int nIni, int D) { return ((size_t)qt_depth_off(nIni, D + 1) * 12 + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t qt_counts_best_off(int nIni, int D) { return ((size_t)qt_depth_off(nIni, D + 1) * 4 + 7) & ~(size_t)7; }
+
+__global__ __launch_bounds__(256) void k_qt_bins(FrameGeom g, CountLevels cl, const uint32_t* __restrict__ cell_cand,
+                                                 const int* __restrict__ cell_count, unsigned char* __restrict__ scratch)
+{
+    const int level = cl.level[blockIdx.y], f = blockIdx.z;
+    const LevelGeom& L = g.lv[level];
+    const int ncell = L.nCols * L.nRows;
+    const int c = blockIdx.x * 32 + (int)(threadIdx.x >> 3), sub = (int)(threadIdx.x & 7);      // 8 lanes per cell
+    if (c >= ncell) return;
+    const int cnt = cell_count[(size_t)f * g.ncells + L.cell_base + c];
+    if (sub >= cnt) return;
+    const int nIni = L.nIni, D = cl.depth[blockIdx.y];
+    unsigned char* slice = scratch + ((size_t)f * cl.n + blockIdx.y) * cl.stride;
+    int* H = reinterpret_cast<int*>(slice) + qt_depth_off(nIni, D);
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(slice + qt_counts_best_off(nIni, D)) + qt_depth_off(nIni, D);
+    const uint32_t slot0 = (uint32_t)__mul24(c, L.cell_cap);
+    const uint32_t* src = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + slot0;
+    const int ci = L.nCols > 1 ? (int)__umulhi((uint32_t)c, L.rcp_ncols) : c, cj = c - __mul24(ci, L.nCols);
+    const int xc = __mul24(cj, L.wCell) + 3, yc = __mul24(ci, L.hCell) + 3;
+    const float hX = L.hX;
+    for (int j = sub; j < cnt; j += 8) {
+        const uint32_t u = src[j];
+        const int x = xc + (int)((u >> 8) & 0xff), y = yc + (int)(u >> 16);
+        int r = (int)__fdiv_rn((float)x, hX);                      // :515-519
+        r = min(max(r, 0), nIni - 1);
+        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.height;
+        int path = r;
+        for (int d = 0; d < D; d++) {
+            const int hx = ceil_half(x1 - x0), hy = ceil_half(y1 - y0);
+            const int right = x < x0 + hx ? 0 : 1, low = y < y0 + hy ? 0 : 1;
+            if (right) x0 = (short)(x0 + hx); else x1 = (short)(x0 + hx);
+            if (low) y0 = (short)(y0 + hy); else y1 = (short)(y0 + hy);
+            path = path * 4 + right + 2 * low;
+        }
+        atomicAdd(&H[path], 1);
+        atomicMax(&B[path], ((unsigned long long)(u & 0xff) << 32) | (unsigned long long)(0xFFFFFFFFu - (slot0 + (uint32_t)j)));
+    }
+}
+
+// dynamic LDS of k_quadtree_counts for M nodes
+__host__ __device__ inline size_t qt_counts_lds(int M_)
+{
+    const size_t M = (size_t)M_;
+    return 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 64 * 4 + 2 * M * 4 + 2 * M * 2 + 2 * M * 2 + 2 * M + M + 64;
+}
+
+// Returns true when the level is done; false (nothing written) when a node at the leaves' depth would have to be
+// split, and the caller then runs the passes over the keys.  Uniform over the workgroup.  smem: qt_counts_lds(M) bytes.
+template <int NT>
+__device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const CountLevels& cl, int slot, int level, int f,
+                                                     const uint32_t* __restrict__ cell_cand, uint2* __restrict__ kp_stage,
+                                                     int* __restrict__ level_count, int* __restrict__ level_ncand,
+                                                     unsigned char* __restrict__ scratch, unsigned char* smem)
+{
+    const int tid = threadIdx.x;
+    const LevelGeom& L = g.lv[level];
+    const int M = g.max_nodes, N = L.nfeat, nIni = L.nIni, D = cl.depth[slot];
+    int* s_cc = reinterpret_cast<int*>(smem);                          // 4*M child occupancy
+    int* s_cnt = s_cc + 4 * M;                                         // 2*M keys per node (two lists)
+    int* s_A = s_cnt + 2 * M;                                          // M
+    int* s_B = s_A + M;                                                // M
+    int* s_C = s_B + M;                                                // M
+    uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                // M (only while ranking)
+    int* s_var = s_C + M;                                              // 64
+    int* s_path = s_var + 64;                                          // 2*M
+    short* s_cidx = reinterpret_cast<short*>(s_path + 2 * M);          // 2*M
+    unsigned short* s_order = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);   // M
+    unsigned short* s_cand = s_order + M;                              // M
+    unsigned char* s_depth = reinterpret_cast<unsigned char*>(s_cand + M);         // 2*M
+    unsigned char* s_fl = s_depth + 2 * M;                             // M
+    int* s_tmp = s_var + 16;
+    // s_var[4]=size [5]=phase2 [6]=finish [7]=cntlt [8]=a node at depth D would have to be split
+
+    unsigned char* slice = scratch + ((size_t)f * cl.n + slot) * cl.stride;
+    int* H = reinterpret_cast<int*>(slice);
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(slice + qt_counts_best_off(nIni, D));
+    // sums and maxima of the shallower depths
+    for (int d = D - 1; d >= 0; d--) {
+        const int o = qt_depth_off(nIni, d), oc = qt_depth_off(nIni, d + 1), nd_ = nIni << (2 * d);
+        for (int p = tid; p < nd_; p += NT) {
+            const int4 h = *reinterpret_cast<const int4*>(H + oc + 4 * p);
+            H[o + p] = h.x + h.y + h.z + h.w;
+            const unsigned long long* b = B + oc + 4 * p;
+            B[o + p] = max(max(b[0], b[1]), max(b[2], b[3]));
+        }
+        __syncthreads();
+    }
+    // ---- root nodes (:492-534)
+    for (int r = tid; r < nIni; r += NT) { s_A[r] = H[r]; s_B[r] = H[r] > 0; }
+    if (tid == 0) {
+        int n = 0;
+        for (int r = 0; r < nIni; r++) n += H[r];
+        level_ncand[f * kMaxLevels + level] = n;
+    }
+    __syncthreads();
+    int size = lds_excl_scan<NT>(s_B, nIni, s_tmp);
+    int cur = 0;
+    for (int r = tid; r < nIni; r += NT)
+        if (s_A[r] > 0) {
+            const int pos = s_B[r];
+            s_cnt[pos] = s_A[r];
+            s_cidx[pos] = -1;
+            s_path[pos] = r;
+            s_depth[pos] = 0;
+        }
+    if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; s_var[8] = 0; }
+    __syncthreads();
+
+    // ---- splitting steps: as in quadtree_body, the child occupancy read from the sums
+    while (true) {
+        size = s_var[4];
+        const int phase2 = s_var[5];
+        int* cc_cur = s_cnt + cur * M;
+        int* cn_nxt = s_cnt + (cur ^ 1) * M;
+        short* ci_cur = s_cidx + cur * M;
+        short* ci_nxt = s_cidx + (cur ^ 1) * M;
+        int* pa_cur = s_path + cur * M;
+        int* pa_nxt = s_path + (cur ^ 1) * M;
+        unsigned char* de_cur = s_depth + cur * M;
+        unsigned char* de_nxt = s_depth + (cur ^ 1) * M;
+
+        for (int p = tid; p < size; p += NT) {
+            const int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
+            s_fl[p] = (unsigned char)e;
+            s_A[p] = e;
+            int4 occ = make_int4(0, 0, 0, 0);
+            if (e) {
+                const int d = de_cur[p];
+                if (d >= D) s_var[8] = 1;
+                else occ = *reinterpret_cast<const int4*>(H + qt_depth_off(nIni, d + 1) + 4 * pa_cur[p]);
+            }
+            s_cc[4 * p] = occ.x; s_cc[4 * p + 1] = occ.y; s_cc[4 * p + 2] = occ.z; s_cc[4 * p + 3] = occ.w;
+        }
+        if (tid == 0) s_var[7] = 0;
+        __syncthreads();
+        if (s_var[8]) {                                    // deeper than the leaves: the passes over the keys take this level
+            __syncthreads();
+            return false;
+        }
+        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
+        if (!phase2) {
+            for (int p = tid; p < size; p += NT)
+                if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
+            __syncthreads();
+        } else {
+            const int m = norder;
+            for (int p = tid; p < size; p += NT)
+                if (s_fl[p]) {
+                    s_cand[s_A[p]] = (unsigned short)p;
+                    s_key[s_A[p]] = (uint32_t)cc_cur[p];
+                    s_B[s_A[p]] = ci_cur[p];
+                }
+            __syncthreads();
+            // rank in (size, creation) descending order: G lanes share one candidate's m comparisons
+            int G = 1;
+            while (G < 64 && m * (2 * G) <= NT) G *= 2;
+            for (int i0 = 0; i0 < m; i0 += NT / G) {
+                const int i = i0 + tid / G, sub = tid & (G - 1);
+                int r = 0;
+                if (i < m) {
+                    const uint32_t ki = s_key[i];
+                    const int ci = s_B[i];
+                    for (int j = sub; j < m; j += G) {
+                        const uint32_t kj = s_key[j];
+                        r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                    }
+                }
+                for (int d = 1; d < G; d <<= 1) r += __shfl_xor(r, d, 64);
+                if (i < m && sub == 0) s_order[r] = s_cand[i];
+            }
+            __syncthreads();
+            for (int s = tid; s < m; s += NT) {
+                const int p = s_order[s];
+                s_B[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0) - 1;
+                s_C[s] = s_B[s];
+            }
+            __syncthreads();
+            lds_excl_scan<NT>(s_C, m, s_tmp);
+            int below = 0;
+            for (int s = tid; s < m; s += NT) below += (size + s_C[s] + s_B[s] < N);
+            if (below) atomicAdd(&s_var[7], below);
+            __syncthreads();
+            norder = min(s_var[7] + 1, m);
+            for (int p = tid; p < size; p += NT) s_fl[p] = 0;
+            __syncthreads();
+            for (int s = tid; s < norder; s += NT) s_fl[s_order[s]] = 1;
+            __syncthreads();
+        }
+        for (int s = tid; s < norder; s += NT) {
+            const int p = s_order[s];
+            s_A[s] = ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) |
+                     (((s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1)) << 16);
+        }
+        for (int p = tid; p < size; p += NT) s_C[p] = !s_fl[p];
+        __syncthreads();
+        int both, nold;
+        lds_excl_scan2<NT>(s_A, norder, s_C, size, s_tmp, &both, &nold);
+        const int totalch = both & 0xffff, ncreated = both >> 16;
+        const int newsize = totalch + nold;
+        for (int s = tid; s < norder; s += NT) {
+            const int p = s_order[s];
+            const int nch = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
+            int pos = totalch - ((s_A[s] & 0xffff) + nch);   // children of later parents come first
+            int cb = s_A[s] >> 16;
+            int cpos[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int qd = 3; qd >= 0; qd--)
+                if (s_cc[4 * p + qd] > 0) {
+                    cn_nxt[pos] = s_cc[4 * p + qd];
+                    ci_nxt[pos] = -1;
+                    pa_nxt[pos] = 4 * pa_cur[p] + qd;
+                    de_nxt[pos] = (unsigned char)(de_cur[p] + 1);
+                    cpos[qd] = pos;
+                    pos++;
+                }
+#pragma unroll
+            for (int qd = 0; qd < 4; qd++)
+                if (s_cc[4 * p + qd] > 1) ci_nxt[cpos[qd]] = (short)(cb++);
+        }
+        for (int p = tid; p < size; p += NT)
+            if (!s_fl[p]) {
+                const int pos = totalch + s_C[p];
+                cn_nxt[pos] = cc_cur[p];
+                ci_nxt[pos] = -1;
+                pa_nxt[pos] = pa_cur[p];
+                de_nxt[pos] = de_cur[p];
+            }
+        if (tid == 0) {
+            s_var[4] = newsize;
+            if (newsize >= N || newsize == size) s_var[6] = 1;
+            else if (!phase2 && newsize + 3 * ncreated > N) s_var[5] = 1;
+        }
+        cur ^= 1;
+        __syncthreads();
+        if (s_var[6]) break;
+    }
+
+    // ---- best key of every node (:689-710): the maximum over its leaves, decoded from the candidate slot
+    size = s_var[4];
+    const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
+    uint2* stage = kp_stage + (size_t)f * g.kp_per_frame + L.kp_base;
+    for (int p = tid; p < size && p < L.kp_cap; p += NT) {
+        const unsigned long long b = B[qt_depth_off(nIni, s_depth[cur * M + p]) + s_path[cur * M + p]];
+        const uint32_t slot = 0xFFFFFFFFu - (uint32_t)(b & 0xFFFFFFFFull);
+        const uint32_t u = cands[slot];
+        const int c = (int)(slot / (uint32_t)L.cell_cap);
+        const int ci = c / L.nCols, cj = c - ci * L.nCols;
+        const int x = cj * L.wCell + 3 + (int)((u >> 8) & 0xff), y = ci * L.hCell + 3 + (int)(u >> 16);
+        stage[p] = make_uint2((uint32_t)x | ((uint32_t)y << 16), (uint32_t)(b >> 32));
+    }
+    if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
+    return true;
+}
+
 // NB = bits of a node index in a key's node word (node | quadrant << NB, 16 bits in all).  NB = 11: the node
 // arrays of up to 2048 nodes live in LDS.  NB = 14: levels asked for more features than that keep the same arrays
 // in a per-workgroup slice of global memory (gscratch): far slower, but the result is the same and no setting is refused
@@ -1129,7 +1406,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                                                   uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,
                                                   uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage,
                                                   int* __restrict__ level_count, int* __restrict__ level_ncand,
-                                                  int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride)
+                                                  int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride,
+                                                  const CountLevels& cl, unsigned char* __restrict__ count_scratch)
 {
     extern __shared__ __align__(16) unsigned char smem_lds[];
     unsigned char* const smem = NB > 11 ? gscratch + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * gstride : smem_lds;
@@ -1140,6 +1418,20 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (level >= g.nlevels || L.width == 0) {
         if (tid == 0) { level_count[f * kMaxLevels + level] = 0; level_ncand[f * kMaxLevels + level] = 0; }
         return;
+    }
+    // A level with many times more candidates than features to keep runs on node counts (k_qt_bins has filled the
+    // leaves): its tree stays shallow.  The passes over the keys below serve it only if the tree grows deeper than the
+    // leaves after all; a level that keeps most of its candidates splits down to single keys and goes there directly.
+    if (NB == 11 && cl.n > 0 && cl.slot[level] >= 0) {
+        const int* cnts = cell_count + (size_t)f * g.ncells + L.cell_base;
+        const int ncells = L.nCols * L.nRows;
+        int part = 0, total;
+        for (int c = tid; c < ncells; c += NT) part += cnts[c];
+        (void)block_excl_scan<NT>(part, reinterpret_cast<int*>(smem_lds), &total);
+        __syncthreads();
+        if (total >= cl.min_ratio * L.nfeat &&
+            quadtree_counts_body<NT>(g, cl, cl.slot[level], level, f, cell_cand, kp_stage, level_count, level_ncand, count_scratch, smem_lds))
+            return;
     }
     const int M = g.max_nodes;
     // LDS carve-up (8-byte items first; s_best shares s_cc, s_key shares s_C)
@@ -1505,8 +1797,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
 #define QUADTREE_PARAMS FrameGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_count,          \
                         int* __restrict__ cell_off, uint32_t* __restrict__ key_xy, uint8_t* __restrict__ key_resp,      \
                         uint16_t* __restrict__ key_node, uint2* __restrict__ kp_stage, int* __restrict__ level_count,   \
-                        int* __restrict__ level_ncand, int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride
-#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds, gscratch, gstride
+                        int* __restrict__ level_ncand, int off_in_lds, unsigned char* __restrict__ gscratch, size_t gstride, \
+                        CountLevels cl, unsigned char* __restrict__ count_scratch
+#define QUADTREE_ARGS g, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, off_in_lds, gscratch, gstride, cl, count_scratch
 // Two shapes of the same body.  256 threads x 10 register keys (91 VGPRs, 5 wavefronts per SIMD) is
 // the throughput shape for batches.  1024 threads x 3 register keys shortens the per-key passes of
 // a lone workgroup: the latency shape for a handful of frames, where the device is mostly idle.
@@ -1894,16 +2187,54 @@ size_t quadtree_scratch_stride(const FrameGeom& g)
     return (quadtree_fixed_lds(g.max_nodes) + ((size_t)max_level_cells(g) + 1) * 4 + 255) & ~(size_t)255;
 }
 
+// levels whose quadtree runs on node counts: many cells (so, as a rule, many thousands of candidates) and node arrays
+// that fit LDS; depth of the leaves: as deep as kQtLeafBins leaves per level allow
+constexpr int kQtCountCells = 800, kQtLeafBins = 32768;
+void quadtree_count_levels(const FrameGeom& g, CountLevels& cl)
+{
+    cl = CountLevels{};
+    for (int l = 0; l < kMaxLevels; l++) cl.slot[l] = -1;
+    // read per geometry (tests switch them inside one process)
+    const bool off = getenv("ORBX_QT_NO_COUNTS") != nullptr;
+    const int min_cells = getenv("ORBX_QT_COUNT_CELLS") ? atoi(getenv("ORBX_QT_COUNT_CELLS")) : kQtCountCells;
+    if (off || g.max_nodes > kMaxNodes) return;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        if (L.width == 0 || L.nCols * L.nRows < min_cells) continue;
+        int D = 0;
+        const int leaf_bins = getenv("ORBX_QT_LEAF_BINS") ? atoi(getenv("ORBX_QT_LEAF_BINS")) : kQtLeafBins;
+        while (D < 8 && (L.nIni << (2 * (D + 1))) <= leaf_bins) D++;
+        if (D < 3) continue;
+        cl.level[cl.n] = l;
+        cl.min_ratio = getenv("ORBX_QT_COUNT_RATIO") ? atoi(getenv("ORBX_QT_COUNT_RATIO")) : 8;
+        cl.slot[l] = cl.n;
+        cl.depth[cl.n] = D;
+        cl.max_cells = std::max(cl.max_cells, L.nCols * L.nRows);
+        cl.stride = std::max(cl.stride, qt_counts_bytes(L.nIni, D));
+        cl.n++;
+    }
+}
+
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
-                     int* level_ncand, int nframes, unsigned char* gscratch, hipStream_t s)
+                     int* level_ncand, int nframes, unsigned char* gscratch, const CountLevels* cl_in, unsigned char* count_scratch,
+                     hipStream_t s)
 {
     dim3 grid(nframes, kMaxLevels);
     int off_in_lds = 0;
+    CountLevels cl{};
+    for (int l = 0; l < kMaxLevels; l++) cl.slot[l] = -1;
+    if (cl_in && cl_in->n > 0 && count_scratch && g.max_nodes <= kMaxNodes) {
+        // the leaves of the levels that run on node counts: cleared, then filled by all keys in parallel
+        cl = *cl_in;
+        (void)hipMemsetAsync(count_scratch, 0, (size_t)nframes * cl.n * cl.stride, s);
+        hipLaunchKernelGGL(k_qt_bins, dim3((cl.max_cells + 31) / 32, cl.n, nframes), dim3(256), 0, s, g, cl, cell_cand,
+                           cell_count, count_scratch);
+    }
     if (g.max_nodes > kMaxNodes) {      // node arrays (and the cell offsets behind them) in global memory
         hipLaunchKernelGGL(k_quadtree_big, grid, dim3(1024), 0, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
                            key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, 1, gscratch,
-                           quadtree_scratch_stride(g));
+                           quadtree_scratch_stride(g), cl, count_scratch);
         return;
     }
     size_t lds = quadtree_total_lds(g, &off_in_lds);
@@ -1915,13 +2246,16 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     const int wide_max = e_wide ? atoi(e_wide) : 32, mid_max = e_mid ? atoi(e_mid) : 112;
     if (nframes <= wide_max)
         hipLaunchKernelGGL(k_quadtree_wide, grid, dim3(1024), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0,
+                           cl, count_scratch);
     else if (nframes <= mid_max)
         hipLaunchKernelGGL(k_quadtree_mid, grid, dim3(512), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0,
+                           cl, count_scratch);
     else
         hipLaunchKernelGGL(k_quadtree, grid, dim3(256), lds, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,
-                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0);
+                           key_node, reinterpret_cast<uint2*>(kp_stage), level_count, level_ncand, off_in_lds, nullptr, (size_t)0,
+                           cl, count_scratch);
 }
 
 int quadtree_prepare(int max_nodes)

@@ -24,6 +24,17 @@ struct FastLds {
     int fixed_pitch;               // 1: the pitches are the compile-time ones of the specialised kernel
 };
 
+// levels of a geometry whose quadtree runs on node counts (k_qt_bins + k_quadtree_counts)
+struct CountLevels {
+    int n;                      // how many
+    int level[kMaxLevels];      // which
+    int slot[kMaxLevels];       // level -> its place in level[] / depth[], -1 for the other levels
+    int depth[kMaxLevels];      // depth of the leaves
+    int max_cells;              // most FAST cells on one of them
+    int min_ratio;              // a level takes this form only with at least min_ratio x nfeat candidates
+    size_t stride;              // bytes of scratch per (frame, listed level)
+};
+
 struct ScaleTab { float v[kMaxLevels]; };
 
 int upload_constant_tables(const int* gauss7, const int* umax16, hipStream_t s);
@@ -46,7 +57,9 @@ size_t quadtree_lds_bytes(int max_nodes);
 int quadtree_prepare(int max_nodes);
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
                      uint32_t* key_xy, uint8_t* key_resp, uint16_t* key_node, void* kp_stage, int* level_count,
-                     int* level_ncand, int nframes, unsigned char* gscratch, hipStream_t s);
+                     int* level_ncand, int nframes, unsigned char* gscratch, const CountLevels* cl, unsigned char* count_scratch,
+                     hipStream_t s);
+void quadtree_count_levels(const FrameGeom& g, CountLevels& cl);
 size_t quadtree_scratch_stride(const FrameGeom& g);
 void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
                         const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,

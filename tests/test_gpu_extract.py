@@ -444,6 +444,32 @@ def test_4k_8000_features():
     ex.close()
 
 
+@pytest.mark.parametrize("ratio", ["0", "3"])
+def test_quadtree_on_node_counts(monkeypatch, ratio):
+    """Levels with very many candidates run DistributeOctTree on node counts (leaf bins filled by all keys in
+    parallel); here that form is forced on every level of ordinary geometries.  ratio 0: also on levels that keep
+    nearly all their candidates, whose trees grow deeper than the leaves, so that the hand-over to the passes over
+    the keys inside the same workgroup runs too.  Shallow leaves (512 bins) make that hand-over frequent."""
+    from orb_slam_amd import ORBextractor
+    monkeypatch.setenv("ORBX_QT_COUNT_CELLS", "1")
+    monkeypatch.setenv("ORBX_QT_COUNT_RATIO", ratio)
+    cases = [(752, 480, 1000, 1234, {}), (1241, 376, 2000, 777, {}), (640, 200, 300, 5, {}), (1600, 1200, 500, 8, dict(nrect=900))]
+    for bins in ("32768", "512"):
+        monkeypatch.setenv("ORBX_QT_LEAF_BINS", bins)
+        for w, h, nfeat, seed, kw in cases:
+            imgs = np.stack([synthetic_frame(w, h, seed + i, **kw) for i in range(3)])
+            imgs[2, : h // 2] = np.random.default_rng(seed).integers(0, 256, size=(h // 2, w), dtype=np.uint8)   # noise: a crowd of candidates
+            ex = ORBextractor(nfeat, 1.2, 8, 20, 7)
+            orc = Oracle(nfeat, 1.2, 8, 20, 7)
+            res = ex.extract_batch(imgs)
+            for i in range(3):
+                kps_o, desc_o = orc.extract(imgs[i], literal=True, cap=nfeat + 1000)
+                assert np.array_equal(ex.debug_level_counts(frame=i), orc.last_level_counts()), (w, h, i)
+                _assert_features(res[i][0], res[i][1], kps_o, desc_o)
+                assert np.array_equal(res[i][1], desc_o)
+            ex.close()
+
+
 def test_small_feature_budget_and_tiny_levels():
     """nfeatures = 40 (Tracking::updateORBExtractor re-creates extractors with small budgets):
     N per level below 4*nIni, and a 200x150 image whose top levels are too small to search."""

@@ -12,6 +12,11 @@ cp $P/pmc_sq_tcp_per_launch.txt profiles/${TAG}_pmc_sq_tcp_per_launch.txt
 cp $P/pmc_fetch_write_per_launch.txt profiles/${TAG}_pmc_fetch_write_per_launch.txt
 python3 tools/trace_filter.py $P/stats/bench_kernel_trace.csv k_fast_blur > profiles/${TAG}_fast_blur_by_grid_default_run.txt
 python3 tools/trace_filter.py $P/stats_headline/bench_kernel_trace.csv k_fast_blur > profiles/${TAG}_fast_blur_by_grid_headline_only_run.txt
+cp $P/stats_frame/fb_kernel_stats.csv profiles/${TAG}_frame_steps_kernel_stats.csv
+cp $P/frame_bench_under_rocprof.txt profiles/${TAG}_frame_steps_under_rocprof.txt
+cp $P/stats_4k/bench_kernel_stats.csv profiles/${TAG}_bench_4k_map_kernel_stats.csv
+cp $P/bench_4k_under_rocprof.json profiles/${TAG}_bench_4k_map_under_rocprof.json
+cp $P/pmc_match_per_launch.txt profiles/${TAG}_pmc_match_per_launch.txt
 cp $P/traffic.json profiles/traffic.json
 cp $P/issue.json profiles/issue.json
 ls -la profiles

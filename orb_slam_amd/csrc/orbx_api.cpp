@@ -81,6 +81,23 @@ struct orbx_ctx {
     int cap_frames = 0;
     DevBuf pyr, blur, cell_cand, cell_count, cell_off, key_xy, key_resp, key_node, kp_stage, level_count, level_ncand, qt_scratch;
     DevBuf qt_counts;               // quadtree on node counts: per-launch scratch (leaves, sums and best keys)
+    // The launch sequence of a small host-fed call, recorded once as a HIP graph and replayed: a lone frame is a
+    // chain of a dozen dependent launches of a few microseconds each, and issuing them one by one leaves the
+    // device waiting for the host.  Valid for one set of arguments (`graph_key`); rebuilt when any of them changes.
+    struct GraphKey {
+        const void *base = nullptr, *stream = nullptr;
+        const void *pyr = nullptr, *blur = nullptr, *cand = nullptr, *kp_stage = nullptr, *counts = nullptr;
+        int nframes = 0, w = 0, h = 0, cap = 0;
+        unsigned long long switches = 0;      // the diagnostic switches that run_batch reads per call
+        bool operator==(const GraphKey& o) const
+        {
+            return switches == o.switches && base == o.base && stream == o.stream && pyr == o.pyr && blur == o.blur && cand == o.cand &&
+                   kp_stage == o.kp_stage && counts == o.counts && nframes == o.nframes && w == o.w && h == o.h && cap == o.cap;
+        }
+    };
+    GraphKey graph_key, graph_seen;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_broken = false;      // a capture or an instantiation failed once: plain launches from then on
     CountLevels count_levels{};
 
     // staging for the host-buffer entry points
@@ -448,6 +465,78 @@ hipError_t finish(orbx_ctx* c)
     return e;
 }
 
+void drop_graph(orbx_ctx* c)
+{
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    c->graph_exec = nullptr;
+    c->graph_key = orbx_ctx::GraphKey{};
+    c->graph_seen = orbx_ctx::GraphKey{};
+}
+
+// run_batch for a small host-fed call on the staging block `base`: as a recorded graph from the second call with the
+// same arguments on.  The first call with new arguments runs the plain launches (they may size buffers, which a
+// capture must not), the second one records them, later ones replay.
+int run_small_batch(orbx_ctx* c, uint8_t* base, size_t o_in, size_t o_k, size_t o_d, int32_t* hn, int nframes, int w, int h,
+                    size_t fbytes, int cap)
+{
+    static const bool no_graph = getenv("ORBX_NO_GRAPH") != nullptr;
+    auto plain = [&]() {
+        return run_batch(c, base + o_in, nframes, w, h, w, fbytes, reinterpret_cast<orbx_keypoint*>(base + o_k), base + o_d, cap,
+                         hn, false);
+    };
+    if (no_graph || c->graph_broken || c->stage_timing) return plain();
+    orbx_ctx::GraphKey key;
+    key.base = base; key.stream = c->stream; key.nframes = nframes; key.w = w; key.h = h; key.cap = cap;
+    for (const char* name : {"ORBX_FUSE_MAX", "ORBX_QT_WIDE_MAX", "ORBX_QT_MID_MAX", "ORBX_OVERLAP", "ORBX_OLD_RESIZE"}) {
+        const char* v = getenv(name);
+        key.switches = key.switches * 1099511628211ull + 1469598103934665603ull;
+        for (; v && *v; v++) key.switches = (key.switches ^ (unsigned char)*v) * 1099511628211ull;
+    }
+    auto fill = [&](orbx_ctx::GraphKey& k) {
+        k.pyr = c->pyr.p; k.blur = c->blur.p; k.cand = c->cell_cand.p; k.kp_stage = c->kp_stage.p; k.counts = c->qt_counts.p;
+    };
+    fill(key);
+    if (c->graph_exec && c->graph_key == key && c->gw == w && c->gh == h) {
+        HIPCHECK(c, hipGraphLaunch(c->graph_exec, c->stream));
+        c->last_nframes = nframes;
+        c->have_pyramid = c->have_features = true;
+        c->h_pyr_frame = -1;
+        return ORBX_OK;
+    }
+    if (!(c->graph_seen == key) || c->gw != w || c->gh != h) {
+        // new arguments: plain launches now, a recording next time if they come again unchanged
+        if (c->graph_exec) drop_graph(c);
+        const int rc = plain();
+        fill(key);                                  // the call may have sized the buffers
+        c->graph_seen = key;
+        return rc;
+    }
+    if (c->graph_exec) drop_graph(c);
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        c->graph_broken = true;
+        return plain();
+    }
+    const int rc = plain();
+    const hipError_t e_end = hipStreamEndCapture(c->stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    const bool ok = rc == ORBX_OK && e_end == hipSuccess && graph &&
+                    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess && exec;
+    if (graph) (void)hipGraphDestroy(graph);
+    if (!ok) {
+        (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
+        c->graph_broken = true;
+        if (rc != ORBX_OK) return rc;
+        return plain();                             // nothing has run yet: the capture only recorded
+    }
+    c->graph_exec = exec;
+    c->graph_key = key;
+    HIPCHECK(c, hipGraphLaunch(c->graph_exec, c->stream));
+    return ORBX_OK;
+}
+
 int check_frame_args(orbx_ctx* c, int nframes, int w, int h, int stride)
 {
     if (!c) return ORBX_ERR_INVALID;
@@ -523,6 +612,7 @@ void orbx_destroy(orbx_ctx* c)
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],
                       &c->stereo_listed, &c->stereo_rows};
+    drop_graph(c);
     for (DevBuf* b : bufs) b->release();
     if (c->pin) (void)hipHostFree(c->pin);
     if (c->h_pyr) (void)hipHostFree(c->h_pyr);
@@ -644,8 +734,7 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
                 std::memcpy(base + o_in + f * fbytes + (size_t)r * w, imgs[f] + (size_t)r * stride, (size_t)w);
         int32_t* hn = reinterpret_cast<int32_t*>(base + o_n);
         for (int f = 0; f < nframes; f++) hn[f] = 0;
-        rc = run_batch(c, base + o_in, nframes, w, h, w, fbytes, reinterpret_cast<orbx_keypoint*>(base + o_k), base + o_d,
-                       cap_per_frame, hn, false);
+        rc = run_small_batch(c, base, o_in, o_k, o_d, hn, nframes, w, h, fbytes, cap_per_frame);
         if (rc != ORBX_OK) return rc;
         HIPCHECK(c, finish(c));
         // every frame is delivered (the first cap_per_frame keypoints of one that overflows) before

@@ -470,6 +470,47 @@ def test_quadtree_on_node_counts(monkeypatch, ratio):
             ex.close()
 
 
+def test_recorded_launch_sequence_follows_its_arguments(oracle, euroc_left, euroc_right, monkeypatch):
+    """Small host-fed calls replay their launch sequence as a recorded graph from the third call with the same
+    arguments on; any change (image size, number of frames, capacity, a batch on the device in between that grows
+    the buffers, a diagnostic switch) must give a fresh sequence, never a stale one."""
+    from orb_slam_amd import ORBextractor
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    small = np.ascontiguousarray(euroc_left[:300, :500])
+    ko_l, do_l = oracle.extract(euroc_left, literal=False)
+    ko_r, do_r = oracle.extract(euroc_right, literal=False)
+    ko_s, do_s = oracle.extract(small, literal=False)
+
+    def check(img, ko, do):
+        kg, dg = ex(img)
+        assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+
+    for _ in range(4):                      # plain, recording, two replays on changing pixels
+        check(euroc_left, ko_l, do_l)
+        check(euroc_right, ko_r, do_r)
+    for _ in range(3):                      # another size, then back
+        check(small, ko_s, do_s)
+    for _ in range(3):
+        check(euroc_left, ko_l, do_l)
+    for _ in range(3):                      # two frames per call
+        res = ex.extract_batch(np.stack([euroc_left, euroc_right]))
+        assert np.array_equal(res[0][0], ko_l) and np.array_equal(res[1][1], do_r)
+    big = ex.extract_batch(np.stack([euroc_left, euroc_right] * 20))       # grows the per-frame buffers
+    assert np.array_equal(big[39][0], ko_r)
+    for _ in range(3):
+        check(euroc_right, ko_r, do_r)
+    monkeypatch.setenv("ORBX_FUSE_MAX", "0")                                # another launch sequence for the same arguments
+    for _ in range(3):
+        check(euroc_left, ko_l, do_l)
+    monkeypatch.delenv("ORBX_FUSE_MAX")
+    check(euroc_left, ko_l, do_l)
+    # the pyramid a caller reads after a replay is that call's
+    ex(euroc_right)
+    oracle.compute_pyramid(euroc_right)
+    assert np.array_equal(ex.pyramid_level(3, border=19), oracle.pyramid_plane(3))
+    ex.close()
+
+
 def test_small_feature_budget_and_tiny_levels():
     """nfeatures = 40 (Tracking::updateORBExtractor re-creates extractors with small budgets):
     N per level below 4*nIni, and a 200x150 image whose top levels are too small to search."""

@@ -8,7 +8,8 @@
 //                      workgroups of the same launch, the 7x7 Gaussian of every level (:1169-1170)
 //                      (k_fast_cells_wave and k_blur_slide: the two on their own)
 //   k_quadtree         DistributeOctTree                               (:488-711)
-//                      (k_quadtree_wide: 1024-thread shape for a handful of frames)
+//                      (k_quadtree_wide / _mid: 1024- / 512-thread shapes for fewer frames; k_qt_bins before it when a
+//                      level has very many candidates: such a level runs on node counts, see quadtree_counts_body)
 //   k_orient_desc      IC_Angle + rBRIEF + output assembly             (:74-150, :1109-1124, :1173-1188)
 //
 // All arithmetic that decides a result is integer, or float written with
@@ -1123,11 +1124,11 @@ __device__ __forceinline__ int ceil_half(int d)
 // and DivideNode (:431-476) sends a key to the quadrant its coordinates select.  So a key's whole path is known in
 // advance, and the number of keys of any node is a sum over the leaves below it.  k_qt_bins (all keys of all
 // frames in parallel, no order) adds every key to its leaf at depth D and keeps the leaf's best key
-// (largest response, first in the reference's append order on ties); k_quadtree_counts builds the sums and
-// maxima of the shallower depths and then runs the same list steps as quadtree_body, reading a node's child
-// occupancy from the sums instead of passing over the keys (80 000 keys x 10 steps on one compute unit
-// otherwise).  A node is (depth, path), path = root * 4^depth + quadrant digits.  If a step has to split a node at
-// depth D the level is flagged and the ordinary kernel, launched next, serves it.
+// (largest response, first in the reference's append order on ties); quadtree_counts_body (the prologue of the
+// quadtree kernels for such a level) builds the sums and maxima of the shallower depths and then runs the same
+// list steps as quadtree_body, reading a node's child occupancy from the sums instead of passing over the keys
+// (80 000 keys x 10 steps on one compute unit otherwise).  A node is (depth, path), path = root * 4^depth +
+// quadrant digits.  If a step has to split a node at depth D, the workgroup goes on with the passes over the keys.
 // ---------------------------------------------------------------------------
 // entries of the depths below d (every depth padded to a multiple of 4 entries, so that a node's four children are one aligned load)
 __host__ __device__ inline int qt_depth_off(int nIni, int d)
@@ -1178,7 +1179,7 @@ __global__ __launch_bounds__(256) void k_qt_bins(FrameGeom g, CountLevels cl, co
     }
 }
 
-// dynamic LDS of k_quadtree_counts for M nodes
+// LDS of quadtree_counts_body for M nodes (less than the node arrays of the key passes, whose allocation it uses)
 __host__ __device__ inline size_t qt_counts_lds(int M_)
 {
     const size_t M = (size_t)M_;

@@ -24,7 +24,7 @@ struct FastLds {
     int fixed_pitch;               // 1: the pitches are the compile-time ones of the specialised kernel
 };
 
-// levels of a geometry whose quadtree runs on node counts (k_qt_bins + k_quadtree_counts)
+// levels of a geometry whose quadtree runs on node counts (k_qt_bins + quadtree_counts_body inside the quadtree kernels)
 struct CountLevels {
     int n;                      // how many
     int level[kMaxLevels];      // which

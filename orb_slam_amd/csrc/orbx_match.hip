@@ -1110,7 +1110,7 @@ void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, cons
     if (q_stride <= 0) return;
     GridQueryArgs a{qx, qy, qr, qmin, qmax, qdesc, d_nq, Q, q_stride};
     dim3 grid((q_stride + 255) / 256, nbatch);
-    if (!cand_idx && qdesc) {
+    if (!cand_idx && qdesc && stride < (1 << 22)) {        // the key's position field holds 22 bits
         hipLaunchKernelGGL(k_grid_search_coop, dim3((q_stride + 15) / 16, nbatch), dim3(256), 0, s, d_kps, d_desc, d_cell_start,
                            d_cell_list, stride, a, minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl,
                            second_lvl, ncand);

@@ -277,6 +277,205 @@ __global__ __launch_bounds__(64 * kMfmaWaves) void k_match_bruteforce_mfma(
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same sweep on the block-scaled FP4 matrix instruction: v_mfma_scale_f32_32x32x64_f8f6f4 with both operands
+// e2m1 takes 64 bits of the descriptors per instruction at the cycles the i8 form needs for 32, so a 256-bit inner
+// product is four instructions instead of eight, an expanded fragment is half as large and a byte expands through
+// a 256-entry table in LDS.  A set bit becomes the nibble 0b0010 = 1.0 in the trains and 0b1010 = -1.0 in the
+// queries, and the queries' block scale is 2^13, so a common bit contributes -2 * 4096.  Which of a lane's 32
+// nibbles stands for which bit does not matter as long as trains and queries expand alike: the instruction pairs
+// equal positions.
+//
+// The accumulator IS the key.  Row r of a tile starts (C operand, the same in every column) at
+//     1.5 * 2^23 + (|b_r| + 256) * 4096 + position of r in the current run of 4096 train descriptors,
+// all sums stay integers below 2^24 and so exact in f32, and the bit pattern of the result is
+//     0x4B400000 + (|b_r| + 256 - 2 <a, b_r>) * 4096 + position:
+// ordered like (distance, index) for one query, so the best two are kept by comparing accumulator registers as
+// they come, without a shift or an add per pair.  After every 4096 train descriptors the two survivors are
+// rewritten as keys on the index in the whole train set.
+// ---------------------------------------------------------------------------
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v16f_t __attribute__((ext_vector_type(16)));
+constexpr int kFp4Waves = 4;                    // one k-step (64 bits) of the train tile per wavefront
+static_assert(kFp4Waves == kMfmaWaves, "the two sweeps share a launch grid");
+constexpr int kFp4RunBits = 12;                 // positions per run: 10 bits of distance field above them fill the mantissa below bit 22
+constexpr uint32_t kFp4Base = 0x4B400000u;      // 1.5 * 2^23 as a bit pattern
+
+__device__ __forceinline__ v4i_t expand32_fp4(const uint32_t* __restrict__ lut, uint32_t bits)
+{
+    v4i_t r;
+    r[0] = (int)lut[bits & 0xffu];
+    r[1] = (int)lut[(bits >> 8) & 0xffu];
+    r[2] = (int)lut[(bits >> 16) & 0xffu];
+    r[3] = (int)lut[bits >> 24];
+    return r;
+}
+
+// c_rows: the start values of the tile's 32 rows, one copy per accumulator (a shared read would be kept in registers
+// of its own as the C operand of a first instruction that writes other registers, sixteen more registers per tile)
+template <bool kPartial>
+__device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, const float* __restrict__ c_rows, int lane, int half,
+                                          const v4i_t (&bq)[kMfmaQT][4], int valid_rows, uint32_t (&best)[kMfmaQT],
+                                          uint32_t (&second)[kMfmaQT])
+{
+    constexpr int kScaleA = 0x7f7f7f7f;                         // E8M0 2^0
+    constexpr int kScaleB = (int)0x8c8c8c8cu;                   // E8M0 2^13: twice the unit of the distance field
+    v16f_t acc[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                           // register 4 g + i holds row 8 g + 4 half + i
+            const float4 c = *reinterpret_cast<const float4*>(c_rows + 32 * qt + 8 * g + 4 * half);
+            acc[qt][4 * g] = c.x; acc[qt][4 * g + 1] = c.y; acc[qt][4 * g + 2] = c.z; acc[qt][4 * g + 3] = c.w;
+        }
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const v4i_t a = a_frag[s * 64 + lane];
+        const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+#pragma unroll
+        for (int qt = 0; qt < kMfmaQT; qt++) {
+            const v8i_t b8 = {bq[qt][s][0], bq[qt][s][1], bq[qt][s][2], bq[qt][s][3], 0, 0, 0, 0};
+            acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[qt], 4, 4, 0, kScaleA, 0, kScaleB);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
+#pragma unroll
+            for (int qt = 0; qt < kMfmaQT; qt++) {
+                // the register's bits through an empty asm: the compiler folds plain integer expressions on the bit
+                // pattern of this instruction's result as if all sixteen elements were equal
+                float f = acc[qt][4 * g + i];
+                asm("" : "+v"(f));
+                uint32_t key = __builtin_bit_cast(uint32_t, f);
+                if (kPartial) key = ok ? key : 0xffffffffu;
+                push_key(best[qt], second[qt], key);
+            }
+        }
+}
+
+__global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
+    const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
+    int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
+    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+{
+    __shared__ v4i_t s_a[2][4 * 64];                            // expanded train fragments: [buffer][k-step][lane]
+    __shared__ __align__(16) float s_c[2][32 * kMfmaQT];        // start value of every train row of the tile, per accumulator
+    __shared__ uint32_t s_lut[256];                             // byte -> eight e2m1 values (bit i -> nibble i = 1.0)
+    const int b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v |= ((threadIdx.x >> i) & 1u) << (4 * i + 1);
+        s_lut[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const int nQ = nq ? min(nq[b], q_stride) : Q;
+    const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
+    const int q0 = (blockIdx.x * kFp4Waves + wave) * (32 * kMfmaQT);
+    if (blockIdx.x * kFp4Waves * (32 * kMfmaQT) >= nQ) return;          // whole workgroup past the queries
+    const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
+    const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
+    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
+
+    // queries: this lane's query of every tile, expanded once (B operand: the 32 bits 64 s + 32 half .. of k-step s)
+    v4i_t bq[kMfmaQT][4];
+    int pa[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) {
+        const int qi = min(q0 + 32 * qt + r, nQ - 1);
+        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
+        const uint4 x = qp[0], y = qp[1];
+        const uint32_t qd[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+        pa[qt] = 0;
+#pragma unroll
+        for (int s = 0; s < 8; s++) pa[qt] += __popc(qd[s]);
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            bq[qt][s] = expand32_fp4(s_lut, half ? qd[2 * s + 1] : qd[2 * s]);
+            bq[qt][s] = bq[qt][s] | (bq[qt][s] << 2);          // 0b0010 -> 0b1010: the B operand holds 0 / -1.0
+        }
+    }
+    // best two of the current run (accumulator bit patterns) and of the runs before it (keys on the whole train set)
+    uint32_t best[kMfmaQT], second[kMfmaQT], gbest[kMfmaQT], gsecond[kMfmaQT];
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) { best[qt] = second[qt] = gbest[qt] = gsecond[qt] = 0xffffffffu; }
+    auto fold = [&](int run0) {
+#pragma unroll
+        for (int qt = 0; qt < kMfmaQT; qt++) {
+            const uint32_t kk[2] = {best[qt], second[qt]};
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                if (kk[i] == 0xffffffffu) continue;
+                const uint32_t v = kk[i] - kFp4Base;
+                push_key(gbest[qt], gsecond[qt], ((v >> kFp4RunBits) << 22) | (uint32_t)(run0 + (int)(v & ((1u << kFp4RunBits) - 1))));
+            }
+            best[qt] = second[qt] = 0xffffffffu;
+        }
+    };
+
+    // train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half of the row; wavefront 0 also reads the
+    // whole descriptor for |b|
+    const uint32_t* tp = t + (size_t)b * t_stride * 8;
+    uint32_t mine = 0;
+    uint4 x = make_uint4(0, 0, 0, 0), y = x;
+    auto fetch = [&](int j) {
+        const int ti = min(j + r, j1 - 1);
+        if (wave == 0) {
+            x = reinterpret_cast<const uint4*>(tp)[2 * ti];
+            y = reinterpret_cast<const uint4*>(tp)[2 * ti + 1];
+        } else {
+            mine = tp[8 * (size_t)ti + 2 * wave + half];
+        }
+    };
+    if (j0 < j1) fetch(j0);
+    int buf = 0, run0 = j0;
+    for (int j = j0; j < j1; j += 32, buf ^= 1) {
+        if (wave == 0) {
+            mine = half ? x.y : x.x;
+            const int pb = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
+            // lanes 32.. write the second accumulator's copy
+            s_c[buf][lane] = __builtin_bit_cast(float, kFp4Base + ((uint32_t)(pb + 256) << kFp4RunBits) + (uint32_t)(j - run0 + r));
+        }
+        s_a[buf][wave * 64 + lane] = expand32_fp4(s_lut, mine);
+        if (j + 32 < j1) fetch(j + 32);
+        __syncthreads();
+        if (active) {
+            if (j + 32 <= j1) fp4_sweep<false>(s_a[buf], s_c[buf], lane, half, bq, 32, best, second);
+            else fp4_sweep<true>(s_a[buf], s_c[buf], lane, half, bq, j1 - j, best, second);
+            if (j + 32 - run0 == (1 << kFp4RunBits)) { fold(run0); run0 = j + 32; }
+        }
+    }
+    if (!active) return;
+    fold(run0);
+
+    // the two halves of the wavefront saw different trains of the same query: merge, then restore |a|
+#pragma unroll
+    for (int qt = 0; qt < kMfmaQT; qt++) {
+        const uint32_t ob = __shfl_xor(gbest[qt], 32, 64), os = __shfl_xor(gsecond[qt], 32, 64);
+        push_key(gbest[qt], gsecond[qt], ob);
+        push_key(gbest[qt], gsecond[qt], os);
+        const int qi = q0 + 32 * qt + r;
+        if (half != 0 || qi >= nQ) continue;
+        const uint32_t fix = (uint32_t)(pa[qt] - 256) << 22;
+        const uint32_t kb = gbest[qt] == 0xffffffffu ? kKeyNone : gbest[qt] + fix;
+        const uint32_t ks = gsecond[qt] == 0xffffffffu ? kKeyNone : gsecond[qt] + fix;
+        const size_t o = (size_t)b * q_stride + qi;
+        if (tsplit == 1) {
+            best_idx[o] = (kb >> 22) >= 256u ? -1 : (int32_t)(kb & 0x3FFFFFu);
+            best_dist[o] = (int32_t)(kb >> 22);
+            second_dist[o] = (int32_t)(ks >> 22);
+        } else {
+            uint32_t* p = partial + (((size_t)b * tsplit + blockIdx.y) * q_stride + qi) * 2;
+            p[0] = kb;
+            p[1] = ks;
+        }
+    }
+}
+
 int match_bruteforce_tsplit(int Q, int T, int nbatch)
 {
     // enough workgroups to fill 256 CUs a few times over, chunks of >= 256 train descriptors
@@ -300,8 +499,18 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
     if (!no_mfma && T >= 64 && q_stride >= 32) {
         const int per_wg = kMfmaWaves * 32 * kMfmaQT;
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
-        hipLaunchKernelGGL(k_match_bruteforce_mfma, grid, dim3(64 * kMfmaWaves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
-                           tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+        // The FP4 form has the cheaper sweep and the dearer start (a table in LDS, queries expanded through it): it
+        // takes over from about a thousand train descriptors per workgroup on.  ORBX_MATCH_FORM=i8|fp4 forces one
+        // (read per call: a test compares the two).
+        const int chunk = (T + tsplit - 1) / tsplit;
+        bool fp4 = chunk >= 1024;
+        if (const char* e = getenv("ORBX_MATCH_FORM")) fp4 = e[0] == 'f' ? true : (e[0] == 'i' ? false : fp4);
+        if (!fp4)
+            hipLaunchKernelGGL(k_match_bruteforce_mfma, grid, dim3(64 * kMfmaWaves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride,
+                               d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+        else
+            hipLaunchKernelGGL(k_match_bruteforce_fp4, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride,
+                               d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
     } else {
         dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
         hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,

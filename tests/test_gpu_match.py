@@ -37,8 +37,18 @@ def test_descriptor_distance(matcher, oracle):
         assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
 
 
+FORMS = ["auto", "i8", "fp4"]     # the two matrix-core sweeps of the brute-force search, and the library's own choice
+
+
+@pytest.fixture(params=FORMS)
+def form(request, monkeypatch):
+    if request.param != "auto":
+        monkeypatch.setenv("ORBX_MATCH_FORM", request.param)      # read by the library at every call
+    return request.param
+
+
 @pytest.mark.parametrize("Q,T", [(1000, 1000), (1, 1), (257, 3), (64, 5000), (300, 0), (1000, 20000)])
-def test_bruteforce(matcher, oracle, Q, T):
+def test_bruteforce(matcher, oracle, form, Q, T):
     q = random_descriptors(Q, 1)
     t = map_descriptors(T, q, seed=2) if T else np.zeros((0, 32), np.uint8)
     if T > 10:
@@ -58,7 +68,7 @@ def test_bruteforce_all_bits_differ(matcher, oracle):
     assert (bi == -1).all() and (bd == 256).all()
 
 
-def test_bruteforce_extreme_popcounts(matcher, oracle):
+def test_bruteforce_extreme_popcounts(matcher, oracle, form):
     """Sizes that take the matrix-core sweep, with the extreme cases of its distance identity
     |a| + |b| - 2<a,b>: empty and full descriptors, complements (distance 256, never a match),
     identical sets, a train count that is no multiple of the 32-row tile, ragged query count."""
@@ -86,6 +96,34 @@ def test_bruteforce_extreme_popcounts(matcher, oracle):
     bi, bd, sd = matcher.match_bruteforce(t, t)
     oi, od, os_ = oracle.match_bruteforce(t, t)
     assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_)
+
+
+def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
+    """A train set long enough that one workgroup sweeps more than 4096 descriptors (the FP4 form rewrites its
+    survivors as keys on the whole set at that period): both forms agree on every query, the oracle on a sample
+    of them; equal descriptors sit on both sides of the first period's end, so the tie goes across it."""
+    rng = np.random.default_rng(5)
+    Q, T = 16384, 150017
+    q = rng.integers(0, 256, (Q, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (T, 32), dtype=np.uint8)
+    t[4095] = t[4096] = q[7]
+    t[4096 + 4095] = t[2 * 4096] = q[9]
+    t[T - 1] = q[11]
+    t[100000] = q[13] ^ np.uint8(1)            # one bit per byte off: distance 32, far below a random pair's
+    res = {}
+    for f in ("i8", "fp4"):
+        monkeypatch.setenv("ORBX_MATCH_FORM", f)
+        res[f] = matcher.match_bruteforce(q, t)
+    for a, b in zip(res["i8"], res["fp4"]):
+        assert np.array_equal(a, b)
+    bi, bd, sd = res["fp4"]
+    assert bi[7] == 4095 and bd[7] == 0 and sd[7] == 0
+    assert bi[9] == 4096 + 4095 and sd[9] == 0
+    assert bi[11] == T - 1 and bd[11] == 0
+    assert bi[13] == 100000 and bd[13] == 32
+    n = 200
+    oi, od, os_ = oracle.match_bruteforce(q[:n], t)
+    assert np.array_equal(bi[:n], oi) and np.array_equal(bd[:n], od) and np.array_equal(sd[:n], os_)
 
 
 def _random_csr(rng, Q, T, maxc):
@@ -118,7 +156,7 @@ def test_windowed_and_csr(matcher, oracle):
         assert np.array_equal(g, r)
 
 
-def test_bruteforce_device_batched(ex, matcher, oracle):
+def test_bruteforce_device_batched(ex, matcher, oracle, form):
     torch = pytest.importorskip("torch")
     nb, stride = 5, 700
     rng = np.random.default_rng(11)

@@ -3,12 +3,14 @@
 against 100000 train descriptors, eight frames against the same 100000, and 128 pairs of 1000 x 1000, each with a
 hash of the results.  Usage: match_bench.py [reps]"""
 import hashlib
+import os
 import sys
 import time
 
 import torch
 
-from orb_slam_amd import ORBextractor, ORBmatcher
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from orb_slam_amd import ORBextractor, ORBmatcher  # noqa: E402
 
 
 def main():

@@ -311,29 +311,33 @@ __device__ __forceinline__ v4i_t expand32_fp4(const uint32_t* __restrict__ lut, 
     return r;
 }
 
-// c_rows: the start values of the tile's 32 rows, one copy per accumulator (a shared read would be kept in registers
-// of its own as the C operand of a first instruction that writes other registers, sixteen more registers per tile)
-template <bool kPartial>
+// c_rows: the start values of the tile's 32 rows.  Every accumulator reads them through an offset the compiler cannot
+// see through: one shared read would be kept in registers of its own as the C operand of a first instruction that
+// writes other registers, sixteen more registers per tile.
+template <int QT, bool kPartial>
 __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, const float* __restrict__ c_rows, int lane, int half,
-                                          const v4i_t (&bq)[kMfmaQT][4], int valid_rows, uint32_t (&best)[kMfmaQT],
-                                          uint32_t (&second)[kMfmaQT])
+                                          const v4i_t (&bq)[QT][4], int valid_rows, uint32_t (&best)[QT],
+                                          uint32_t (&second)[QT])
 {
     constexpr int kScaleA = 0x7f7f7f7f;                         // E8M0 2^0
     constexpr int kScaleB = (int)0x8c8c8c8cu;                   // E8M0 2^13: twice the unit of the distance field
-    v16f_t acc[kMfmaQT];
+    v16f_t acc[QT];
 #pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++)
+    for (int qt = 0; qt < QT; qt++) {
+        int row0 = 4 * half;
+        asm("" : "+v"(row0));
 #pragma unroll
         for (int g = 0; g < 4; g++) {                           // register 4 g + i holds row 8 g + 4 half + i
-            const float4 c = *reinterpret_cast<const float4*>(c_rows + 32 * qt + 8 * g + 4 * half);
+            const float4 c = *reinterpret_cast<const float4*>(c_rows + row0 + 8 * g);
             acc[qt][4 * g] = c.x; acc[qt][4 * g + 1] = c.y; acc[qt][4 * g + 2] = c.z; acc[qt][4 * g + 3] = c.w;
         }
+    }
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const v4i_t a = a_frag[s * 64 + lane];
         const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 #pragma unroll
-        for (int qt = 0; qt < kMfmaQT; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             const v8i_t b8 = {bq[qt][s][0], bq[qt][s][1], bq[qt][s][2], bq[qt][s][3], 0, 0, 0, 0};
             acc[qt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[qt], 4, 4, 0, kScaleA, 0, kScaleB);
         }
@@ -344,7 +348,7 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
         for (int i = 0; i < 4; i++) {
             const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
 #pragma unroll
-            for (int qt = 0; qt < kMfmaQT; qt++) {
+            for (int qt = 0; qt < QT; qt++) {
                 // the register's bits through an empty asm: the compiler folds plain integer expressions on the bit
                 // pattern of this instruction's result as if all sixteen elements were equal
                 float f = acc[qt][4 * g + i];
@@ -356,13 +360,14 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
         }
 }
 
+template <int QT>
 __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
     const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
     int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
 {
     __shared__ v4i_t s_a[2][4 * 64];                            // expanded train fragments: [buffer][k-step][lane]
-    __shared__ __align__(16) float s_c[2][32 * kMfmaQT];        // start value of every train row of the tile, per accumulator
+    __shared__ __align__(16) uint32_t s_c[3][32];               // start value (bit pattern) of every train row: [tile mod 3][row]
     __shared__ uint32_t s_lut[256];                             // byte -> eight e2m1 values (bit i -> nibble i = 1.0)
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
@@ -372,20 +377,22 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
         for (int i = 0; i < 8; i++) v |= ((threadIdx.x >> i) & 1u) << (4 * i + 1);
         s_lut[threadIdx.x] = v;
     }
+    constexpr uint32_t kRowBase = kFp4Base + (256u << kFp4RunBits);
+    if (threadIdx.x < 32) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;         // the first tile's rows: positions 0..31 of the first run
     __syncthreads();
     const int nQ = nq ? min(nq[b], q_stride) : Q;
     const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
-    const int q0 = (blockIdx.x * kFp4Waves + wave) * (32 * kMfmaQT);
-    if (blockIdx.x * kFp4Waves * (32 * kMfmaQT) >= nQ) return;          // whole workgroup past the queries
+    const int q0 = (blockIdx.x * kFp4Waves + wave) * (32 * QT);
+    if (blockIdx.x * kFp4Waves * (32 * QT) >= nQ) return;          // whole workgroup past the queries
     const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
     const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
     const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
 
     // queries: this lane's query of every tile, expanded once (B operand: the 32 bits 64 s + 32 half .. of k-step s)
-    v4i_t bq[kMfmaQT][4];
-    int pa[kMfmaQT];
+    v4i_t bq[QT][4];
+    int pa[QT];
 #pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const int qi = min(q0 + 32 * qt + r, nQ - 1);
         const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
         const uint4 x = qp[0], y = qp[1];
@@ -400,12 +407,12 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
         }
     }
     // best two of the current run (accumulator bit patterns) and of the runs before it (keys on the whole train set)
-    uint32_t best[kMfmaQT], second[kMfmaQT], gbest[kMfmaQT], gsecond[kMfmaQT];
+    uint32_t best[QT], second[QT], gbest[QT], gsecond[QT];
 #pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) { best[qt] = second[qt] = gbest[qt] = gsecond[qt] = 0xffffffffu; }
+    for (int qt = 0; qt < QT; qt++) { best[qt] = second[qt] = gbest[qt] = gsecond[qt] = 0xffffffffu; }
     auto fold = [&](int run0) {
 #pragma unroll
-        for (int qt = 0; qt < kMfmaQT; qt++) {
+        for (int qt = 0; qt < QT; qt++) {
             const uint32_t kk[2] = {best[qt], second[qt]};
 #pragma unroll
             for (int i = 0; i < 2; i++) {
@@ -417,44 +424,35 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
         }
     };
 
-    // train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half of the row; wavefront 0 also reads the
-    // whole descriptor for |b|
-    const uint32_t* tp = t + (size_t)b * t_stride * 8;
+    // Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half of the row, and adds that dword's
+    // share of |b_r| to the row's start value, which a wavefront set up one tile ahead (three buffers: the tile being
+    // swept, the tile being built, and the one after it being set up).  Runs of 4096 positions start at j0.
+    const uint32_t* tp = t + (size_t)b * t_stride * 8 + 2 * wave + half;
+    constexpr int kRunMask = (1 << kFp4RunBits) - 1;
     uint32_t mine = 0;
-    uint4 x = make_uint4(0, 0, 0, 0), y = x;
-    auto fetch = [&](int j) {
-        const int ti = min(j + r, j1 - 1);
-        if (wave == 0) {
-            x = reinterpret_cast<const uint4*>(tp)[2 * ti];
-            y = reinterpret_cast<const uint4*>(tp)[2 * ti + 1];
-        } else {
-            mine = tp[8 * (size_t)ti + 2 * wave + half];
-        }
-    };
-    if (j0 < j1) fetch(j0);
-    int buf = 0, run0 = j0;
+    if (j0 < j1) mine = tp[8 * (size_t)min(j0 + r, j1 - 1)];
+    int buf = 0, cb = 0;
     for (int j = j0; j < j1; j += 32, buf ^= 1) {
-        if (wave == 0) {
-            mine = half ? x.y : x.x;
-            const int pb = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
-            // lanes 32.. write the second accumulator's copy
-            s_c[buf][lane] = __builtin_bit_cast(float, kFp4Base + ((uint32_t)(pb + 256) << kFp4RunBits) + (uint32_t)(j - run0 + r));
-        }
+        atomicAdd(&s_c[cb][r], (uint32_t)__popc(mine) << kFp4RunBits);
         s_a[buf][wave * 64 + lane] = expand32_fp4(s_lut, mine);
-        if (j + 32 < j1) fetch(j + 32);
+        const int cn = cb == 2 ? 0 : cb + 1;
+        if (threadIdx.x < 32) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 - j0) & kRunMask) + (int)threadIdx.x);
+        if (j + 32 < j1) mine = tp[8 * (size_t)min(j + 32 + r, j1 - 1)];
         __syncthreads();
         if (active) {
-            if (j + 32 <= j1) fp4_sweep<false>(s_a[buf], s_c[buf], lane, half, bq, 32, best, second);
-            else fp4_sweep<true>(s_a[buf], s_c[buf], lane, half, bq, j1 - j, best, second);
-            if (j + 32 - run0 == (1 << kFp4RunBits)) { fold(run0); run0 = j + 32; }
+            const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
+            if (j + 32 <= j1) fp4_sweep<QT, false>(s_a[buf], c_rows, lane, half, bq, 32, best, second);
+            else fp4_sweep<QT, true>(s_a[buf], c_rows, lane, half, bq, j1 - j, best, second);
+            if (((j + 32 - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
         }
+        cb = cn;
     }
     if (!active) return;
-    fold(run0);
+    fold(j0 + ((j1 - 1 - j0) & ~kRunMask));   // (a whole number of runs: nothing left, and the fold of nothing is harmless)
 
     // the two halves of the wavefront saw different trains of the same query: merge, then restore |a|
 #pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) {
+    for (int qt = 0; qt < QT; qt++) {
         const uint32_t ob = __shfl_xor(gbest[qt], 32, 64), os = __shfl_xor(gsecond[qt], 32, 64);
         push_key(gbest[qt], gsecond[qt], ob);
         push_key(gbest[qt], gsecond[qt], os);
@@ -500,17 +498,19 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
         const int per_wg = kMfmaWaves * 32 * kMfmaQT;
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
         // The FP4 form has the cheaper sweep and the dearer start (a table in LDS, queries expanded through it): it
-        // takes over from about a thousand train descriptors per workgroup on.  ORBX_MATCH_FORM=i8|fp4 forces one
-        // (read per call: a test compares the two).
+        // takes over from a dozen tiles per workgroup on (measured: 313 train descriptors per workgroup 4 % faster, 391
+        // 10 %, 910 26 %; 257 a quarter slower).  ORBX_MATCH_FORM=i8|fp4 forces one (read per call: a test compares
+        // the two).
         const int chunk = (T + tsplit - 1) / tsplit;
-        bool fp4 = chunk >= 1024;
+        bool fp4 = chunk >= 384;
         if (const char* e = getenv("ORBX_MATCH_FORM")) fp4 = e[0] == 'f' ? true : (e[0] == 'i' ? false : fp4);
-        if (!fp4)
+        if (!fp4) {
             hipLaunchKernelGGL(k_match_bruteforce_mfma, grid, dim3(64 * kMfmaWaves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride,
                                d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
-        else
-            hipLaunchKernelGGL(k_match_bruteforce_fp4, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride,
-                               d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+        } else {
+            hipLaunchKernelGGL(k_match_bruteforce_fp4<kMfmaQT>, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T,
+                               t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+        }
     } else {
         dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
         hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,

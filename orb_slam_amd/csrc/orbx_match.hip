@@ -103,6 +103,45 @@ __global__ __launch_bounds__(256) void k_match_merge(const uint32_t* __restrict_
     second_dist[o] = (int32_t)(second >> 22);
 }
 
+// The same for many splits (few queries against a long train set: a thousand queries split 390 ways left four
+// workgroups walking 390 dependent loads each, 99 us; this form 5 us).  Grid (ceil(q_stride/16), nbatch): sixteen
+// queries per workgroup, sixteen threads per query that share the splits (a load instruction of the workgroup reads
+// sixteen runs of 128 contiguous bytes), then the sixteen partial results of a query through LDS.
+__global__ __launch_bounds__(256) void k_match_merge_wide(const uint32_t* __restrict__ partial, int Q, int q_stride,
+                                                          const int32_t* __restrict__ nq, int tsplit,
+                                                          int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
+                                                          int32_t* __restrict__ second_dist)
+{
+    __shared__ uint2 s_k[16][17];
+    const int b = blockIdx.y;
+    const int ql = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int qi = blockIdx.x * 16 + ql;
+    const int nQ = nq ? min(nq[b], q_stride) : Q;
+    uint32_t best = kKeyNone, second = kKeyNone;
+    if (qi < nQ) {
+        const uint2* p = reinterpret_cast<const uint2*>(partial) + (size_t)b * tsplit * q_stride + qi;
+#pragma unroll 4
+        for (int s = g; s < tsplit; s += 16) {
+            const uint2 k = p[(size_t)s * q_stride];
+            push_key(best, second, k.x);
+            push_key(best, second, k.y);
+        }
+    }
+    s_k[g][ql] = make_uint2(best, second);
+    __syncthreads();
+    if (g != 0 || qi >= nQ) return;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        const uint2 k = s_k[i][ql];
+        push_key(best, second, k.x);
+        push_key(best, second, k.y);
+    }
+    const size_t o = (size_t)b * q_stride + qi;
+    best_idx[o] = (best >> 22) >= 256u ? -1 : (int32_t)(best & 0x3FFFFFu);
+    best_dist[o] = (int32_t)(best >> 22);
+    second_dist[o] = (int32_t)(second >> 22);
+}
+
 // ---------------------------------------------------------------------------
 // Brute force on the matrix cores.  Hamming(a, b) = |a| + |b| - 2 <a, b> for bit vectors, and the
 // 256-bit inner products of 32 train x 32 query descriptors are one chain of eight
@@ -517,9 +556,15 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
                            tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
     }
     if (tsplit > 1) {
-        dim3 g2((q_stride + 255) / 256, nbatch);
-        hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, d_partial, Q, q_stride, d_nq, tsplit, d_best_idx,
-                           d_best_dist, d_second_dist);
+        if (tsplit >= 16) {
+            dim3 g2((q_stride + 15) / 16, nbatch);
+            hipLaunchKernelGGL(k_match_merge_wide, g2, dim3(256), 0, s, d_partial, Q, q_stride, d_nq, tsplit, d_best_idx,
+                               d_best_dist, d_second_dist);
+        } else {
+            dim3 g2((q_stride + 255) / 256, nbatch);
+            hipLaunchKernelGGL(k_match_merge, g2, dim3(256), 0, s, d_partial, Q, q_stride, d_nq, tsplit, d_best_idx,
+                               d_best_dist, d_second_dist);
+        }
     }
 }
 

@@ -427,6 +427,11 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
     const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
     const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
 
+    // the first tile's train dwords are on their way while the queries are expanded
+    const uint32_t* tp = t + (size_t)b * t_stride * 8 + 2 * wave + half;
+    uint32_t mine = 0;
+    if (j0 < j1) mine = tp[8 * (size_t)min(j0 + r, j1 - 1)];
+
     // queries: this lane's query of every tile, expanded once (B operand: the 32 bits 64 s + 32 half .. of k-step s)
     v4i_t bq[QT][4];
     int pa[QT];
@@ -466,10 +471,7 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
     // Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half of the row, and adds that dword's
     // share of |b_r| to the row's start value, which a wavefront set up one tile ahead (three buffers: the tile being
     // swept, the tile being built, and the one after it being set up).  Runs of 4096 positions start at j0.
-    const uint32_t* tp = t + (size_t)b * t_stride * 8 + 2 * wave + half;
     constexpr int kRunMask = (1 << kFp4RunBits) - 1;
-    uint32_t mine = 0;
-    if (j0 < j1) mine = tp[8 * (size_t)min(j0 + r, j1 - 1)];
     int buf = 0, cb = 0;
     for (int j = j0; j < j1; j += 32, buf ^= 1) {
         atomicAdd(&s_c[cb][r], (uint32_t)__popc(mine) << kFp4RunBits);

@@ -388,11 +388,10 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
             const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
 #pragma unroll
             for (int qt = 0; qt < QT; qt++) {
-                // the register's bits through an empty asm: the compiler folds plain integer expressions on the bit
-                // pattern of this instruction's result as if all sixteen elements were equal
-                float f = acc[qt][4 * g + i];
-                asm("" : "+v"(f));
-                uint32_t key = __builtin_bit_cast(uint32_t, f);
+                // (through a scalar copy: __builtin_bit_cast applied to the element expression itself reads element 0 of
+                // the vector whatever the index)
+                const float f = acc[qt][4 * g + i];
+                uint32_t key = __float_as_uint(f);
                 if (kPartial) key = ok ? key : 0xffffffffu;
                 push_key(best[qt], second[qt], key);
             }

@@ -126,6 +126,26 @@ def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
     assert np.array_equal(bi[:n], oi) and np.array_equal(bd[:n], od) and np.array_equal(sd[:n], os_)
 
 
+def test_bruteforce_largest_train_set(matcher, oracle, monkeypatch):
+    """2^22 - 1 train descriptors, the most the 22-bit index field of a key holds: the last index is found, in
+    every matrix form, and one more descriptor is refused."""
+    from orb_slam_amd import OrbxError
+    rng = np.random.default_rng(17)
+    Q, T = 40, (1 << 22) - 1
+    q = rng.integers(0, 256, (Q, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (T, 32), dtype=np.uint8)
+    t[T - 1] = q[3]
+    t[T - 2] = q[4] ^ np.uint8(128)
+    oi, od, os_ = oracle.match_bruteforce(q, t)
+    assert oi[3] == T - 1 and od[3] == 0
+    for f in ("i8", "fp4"):
+        monkeypatch.setenv("ORBX_MATCH_FORM", f)
+        bi, bd, sd = matcher.match_bruteforce(q, t)
+        assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_), f
+    with pytest.raises(OrbxError):
+        matcher.match_bruteforce(q, np.zeros((1 << 22, 32), np.uint8))
+
+
 def _random_csr(rng, Q, T, maxc):
     counts = rng.integers(0, maxc + 1, Q)
     counts[rng.integers(0, Q, max(1, Q // 10))] = 0        # ragged: empty lists

@@ -17,6 +17,7 @@ cp $P/frame_bench_under_rocprof.txt profiles/${TAG}_frame_steps_under_rocprof.tx
 cp $P/stats_4k/bench_kernel_stats.csv profiles/${TAG}_bench_4k_map_kernel_stats.csv
 cp $P/bench_4k_under_rocprof.json profiles/${TAG}_bench_4k_map_under_rocprof.json
 cp $P/pmc_match_per_launch.txt profiles/${TAG}_pmc_match_per_launch.txt
+cp $P/pmc_match_fp4_8x8000x100000.txt profiles/${TAG}_pmc_match_fp4_8x8000x100000.txt
 cp $P/traffic.json profiles/traffic.json
 cp $P/issue.json profiles/issue.json
 ls -la profiles

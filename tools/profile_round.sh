@@ -27,8 +27,13 @@ timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT
 # the brute-force matcher alone: matrix pipe and vector issue
 timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_match1 -o pmc -- python3 $ROOT/tools/match_bench.py 3 > $OUT/pmc_match1.log 2>&1
 timeout -s KILL 90 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_match2 -o pmc -- python3 $ROOT/tools/match_bench.py 3 > $OUT/pmc_match2.log 2>&1
+# the FP4 sweep on one shape (8 x 8000 queries against one 100000-point map): counters of one kernel on one grid
+timeout -s KILL 90 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d $OUT/pmc_fp4a -o pmc -- python3 $ROOT/tools/match_one_shape.py > $OUT/pmc_fp4a.log 2>&1
+timeout -s KILL 90 rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_fp4b -o pmc -- python3 $ROOT/tools/match_one_shape.py > $OUT/pmc_fp4b.log 2>&1
+timeout -s KILL 90 rocprofv3 --pmc SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fp4c -o pmc -- python3 $ROOT/tools/match_one_shape.py > $OUT/pmc_fp4c.log 2>&1
 cd $ROOT
 python3 tools/pmc_summary.py $(find $OUT/pmc_match1 $OUT/pmc_match2 -name '*counter_collection.csv') > $OUT/pmc_match_per_launch.txt
+python3 tools/pmc_summary.py $(find $OUT/pmc_fp4a $OUT/pmc_fp4b $OUT/pmc_fp4c -name '*counter_collection.csv') > $OUT/pmc_match_fp4_8x8000x100000.txt
 python3 tools/pmc_summary.py $(find $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_tcp -name '*counter_collection.csv') > $OUT/pmc_sq_tcp_per_launch.txt
 python3 tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name '*counter_collection.csv') > $OUT/pmc_fetch_write_per_launch.txt
 python3 tools/make_traffic.py $(find $OUT/pmc_fetch -name '*counter_collection.csv') $(find $OUT/pmc_write -name '*counter_collection.csv') $OUT/traffic.json > /dev/null

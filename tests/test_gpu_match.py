@@ -199,6 +199,37 @@ def test_bruteforce_device_batched(ex, matcher, oracle, form):
         assert np.array_equal(outs[2][b, :nq[b]].cpu().numpy(), os_)
 
 
+def test_bruteforce_device_batched_empty_sets_and_padded_strides(ex, matcher, oracle, form):
+    """Batches with no queries or no train descriptors at all, counts of 1, and strides larger than the counts:
+    an empty train set answers -1 / 256 / 256, an empty query set writes nothing."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(3)
+    nb, qs, ts = 6, 700, 9000
+    q = rng.integers(0, 256, (nb, qs + 40, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (nb, ts + 100, 32), dtype=np.uint8)
+    nq = np.array([0, 700, 1, 350, 0, 31], np.int32)
+    nt = np.array([9000, 0, 5, 8999, 0, 64], np.int32)
+    dev = torch.device("cuda:0")
+    dq, dt, dnq, dnt = [torch.from_numpy(a).to(dev) for a in (q, t, nq, nt)]
+    outs = [torch.full((nb, qs + 40), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    matcher.match_bruteforce_device(dq, qs, qs + 40, dnq, dt, ts, ts + 100, dnt, nb, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    got = [o.cpu().numpy() for o in outs]
+    for b in range(nb):
+        n = nq[b]
+        assert all((g[b, n:] == -7).all() for g in got)            # nothing written past the batch's queries
+        if n == 0:
+            continue
+        if nt[b] == 0:
+            ref = (np.full(n, -1, np.int32), np.full(n, 256, np.int32), np.full(n, 256, np.int32))
+        else:
+            ref = oracle.match_bruteforce(q[b, :n], t[b, :nt[b]])
+        for g, r in zip(got, ref):
+            assert np.array_equal(g[b, :n], r)
+
+
 def test_stereo_on_extracted_pair(ex, matcher, oracle):
     left, right = synthetic_stereo_pair(752, 480, 4321)
     kl, dl = ex(left)

@@ -398,14 +398,16 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
         }
 }
 
+// (four wavefronts per SIMD: at the 132 registers the compiler would take, three are resident and the sweep of eight
+// frames against one map is 3 % slower)
 template <int QT>
-__global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
+__global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match_bruteforce_fp4(
     const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
     int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
 {
-    __shared__ v4i_t s_a[2][4 * 64];                            // expanded train fragments: [buffer][k-step][lane]
-    __shared__ __align__(16) uint32_t s_c[3][32];               // start value (bit pattern) of every train row: [tile mod 3][row]
+    __shared__ v4i_t s_a[2][2][4 * 64];                         // expanded train fragments: [buffer][tile of the pair][k-step][lane]
+    __shared__ __align__(16) uint32_t s_c[3][64];               // start value (bit pattern) of every train row: [pair mod 3][row]
     __shared__ uint32_t s_lut[256];                             // byte -> eight e2m1 values (bit i -> nibble i = 1.0)
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
         s_lut[threadIdx.x] = v;
     }
     constexpr uint32_t kRowBase = kFp4Base + (256u << kFp4RunBits);
-    if (threadIdx.x < 32) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;         // the first tile's rows: positions 0..31 of the first run
+    if (threadIdx.x < 64) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;         // the first pair's rows: positions 0..63 of the first run
     __syncthreads();
     const int nQ = nq ? min(nq[b], q_stride) : Q;
     const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
@@ -467,23 +469,31 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_match_bruteforce_fp4(
         }
     };
 
-    // Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half of the row, and adds that dword's
-    // share of |b_r| to the row's start value, which a wavefront set up one tile ahead (three buffers: the tile being
-    // swept, the tile being built, and the one after it being set up).  Runs of 4096 positions start at j0.
+    // Two tiles per barrier (one: 4 % slower).  Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half
+    // of the row, and adds that dword's share of |b_r| to the row's start value, which a wavefront set up one pair of
+    // tiles ahead (three buffers: the pair being swept, the pair being built, and the one after it being set up).  Runs
+    // of 4096 positions start at j0.
     constexpr int kRunMask = (1 << kFp4RunBits) - 1;
     int buf = 0, cb = 0;
-    for (int j = j0; j < j1; j += 32, buf ^= 1) {
+    uint32_t mine1 = 0;
+    if (j0 + 32 < j1) mine1 = tp[8 * (size_t)min(j0 + 32 + r, j1 - 1)];
+    for (int j = j0; j < j1; j += 64, buf ^= 1) {
         atomicAdd(&s_c[cb][r], (uint32_t)__popc(mine) << kFp4RunBits);
-        s_a[buf][wave * 64 + lane] = expand32_fp4(s_lut, mine);
+        atomicAdd(&s_c[cb][32 + r], (uint32_t)__popc(mine1) << kFp4RunBits);
+        s_a[buf][0][wave * 64 + lane] = expand32_fp4(s_lut, mine);
+        s_a[buf][1][wave * 64 + lane] = expand32_fp4(s_lut, mine1);
         const int cn = cb == 2 ? 0 : cb + 1;
-        if (threadIdx.x < 32) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 - j0) & kRunMask) + (int)threadIdx.x);
-        if (j + 32 < j1) mine = tp[8 * (size_t)min(j + 32 + r, j1 - 1)];
+        if (threadIdx.x < 64) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 64 - j0) & kRunMask) + (int)threadIdx.x);
+        if (j + 64 < j1) mine = tp[8 * (size_t)min(j + 64 + r, j1 - 1)];
+        if (j + 96 < j1) mine1 = tp[8 * (size_t)min(j + 96 + r, j1 - 1)];
         __syncthreads();
         if (active) {
             const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
-            if (j + 32 <= j1) fp4_sweep<QT, false>(s_a[buf], c_rows, lane, half, bq, 32, best, second);
-            else fp4_sweep<QT, true>(s_a[buf], c_rows, lane, half, bq, j1 - j, best, second);
-            if (((j + 32 - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
+            if (j + 32 <= j1) fp4_sweep<QT, false>(s_a[buf][0], c_rows, lane, half, bq, 32, best, second);
+            else fp4_sweep<QT, true>(s_a[buf][0], c_rows, lane, half, bq, j1 - j, best, second);
+            if (j + 64 <= j1) fp4_sweep<QT, false>(s_a[buf][1], c_rows + 32, lane, half, bq, 32, best, second);
+            else if (j + 32 < j1) fp4_sweep<QT, true>(s_a[buf][1], c_rows + 32, lane, half, bq, j1 - j - 32, best, second);
+            if (((j + 64 - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
         }
         cb = cn;
     }

@@ -143,200 +143,34 @@ __global__ __launch_bounds__(256) void k_match_merge_wide(const uint32_t* __rest
 }
 
 // ---------------------------------------------------------------------------
-// Brute force on the matrix cores.  Hamming(a, b) = |a| + |b| - 2 <a, b> for bit vectors, and the
-// 256-bit inner products of 32 train x 32 query descriptors are one chain of eight
-// v_mfma_i32_32x32x32_i8 over bits expanded to 0/1 bytes.  With the trains as the A operand and
-// the queries as B, lane l of the 32x32 result holds query l & 31 against 16 trains (rows
-// (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)), so the (best, second) update is lane-local: three
-// vector instructions per pair instead of the ~19 of the xor/popcount form.  A wavefront keeps the
-// expanded bytes of kMfmaQT * 32 queries in registers and streams the train tiles past them.
-// The key field during the sweep is |b| - 2 <a, b> + 256 (|a| is the same for every candidate of
-// a query and is added at the end); key order, and therefore the tie rule "smallest distance, then
-// smallest index", is that of k_match_bruteforce.
-// ---------------------------------------------------------------------------
-typedef int v4i_t __attribute__((ext_vector_type(4)));
-typedef int v16i_t __attribute__((ext_vector_type(16)));
-constexpr int kMfmaQT = 2;              // query tiles (of 32) per wavefront
-
-// 16 bits -> 16 bytes of 0/1 (bit i -> byte i)
-__device__ __forceinline__ v4i_t expand16(uint32_t bits16)
-{
-    v4i_t r;
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        r[q] = (int)(__umul24((bits16 >> (4 * q)) & 0xfu, 0x00204081u) & 0x01010101u);
-    return r;
-}
-
-// grid (ceil(q_stride / (kMfmaWaves * 32 * kMfmaQT)), tsplit, nbatch); workgroup = kMfmaWaves wavefronts, each
-// with its own 32 * kMfmaQT queries, all sweeping the same train tiles.  Expanding a train tile to bytes is
-// the largest fixed cost per tile, so the wavefronts split it (8 / kMfmaWaves of the eight k-steps each), park the
-// fragments and the tile's key bases in LDS (double-buffered, one barrier per tile) and every wavefront
-// reads them back.
-constexpr int kMfmaWaves = 4;
-constexpr int kMfmaSteps = 8 / kMfmaWaves;      // k-steps each wavefront expands
-
-template <bool kPartial>
-__device__ __forceinline__ void mfma_sweep(const v4i_t* __restrict__ a_frag, const uint32_t* __restrict__ krow, int lane,
-                                           int half, const v4i_t (&bq)[kMfmaQT][8], int valid_rows,
-                                           uint32_t (&best)[kMfmaQT], uint32_t (&second)[kMfmaQT])
-{
-    v16i_t acc[kMfmaQT];
-#pragma unroll
-    for (int s = 0; s < 8; s++) {
-        const v4i_t a = a_frag[s * 64 + lane];
-#pragma unroll
-        for (int qt = 0; qt < kMfmaQT; qt++) {
-            if (s == 0) {
-                const v16i_t zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-                acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], zero, 0, 0, 0);
-            } else {
-                acc[qt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[qt][s], acc[qt], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        // rows 8g + 4 * half + {0, 1, 2, 3} of the tile are registers 4g .. 4g + 3 of this lane
-        const uint4 K4 = *reinterpret_cast<const uint4*>(krow + 8 * g + 4 * half);
-        const uint32_t K[4] = {K4.x, K4.y, K4.z, K4.w};
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const bool ok = !kPartial || 8 * g + 4 * half + i < valid_rows;
-#pragma unroll
-            for (int qt = 0; qt < kMfmaQT; qt++) {
-                // the queries are expanded to 0 / -1 bytes, so acc = -<a, b> and the key
-                // (|b| + 256 - 2 dot) << 22 | index is one shift-add
-                uint32_t key = ((uint32_t)acc[qt][4 * g + i] << 23) + K[i];
-                if (kPartial) key = ok ? key : 0xffffffffu;
-                push_key(best[qt], second[qt], key);
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(64 * kMfmaWaves) void k_match_bruteforce_mfma(
-    const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
-    int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
-    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
-{
-    __shared__ v4i_t s_a[2][8 * 64];          // expanded train fragments: [buffer][k-step][lane]
-    __shared__ __align__(16) uint32_t s_k[2][32];   // key base of every train row of the tile
-    const int b = blockIdx.z;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
-    const int nQ = nq ? min(nq[b], q_stride) : Q;
-    const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
-    const int q0 = (blockIdx.x * kMfmaWaves + wave) * (32 * kMfmaQT);
-    if (blockIdx.x * kMfmaWaves * (32 * kMfmaQT) >= nQ) return;         // whole workgroup past the queries
-    const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
-    const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
-    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
-
-    // queries: this lane's query of every tile, expanded once (B operand: k-set `half`, column r)
-    v4i_t bq[kMfmaQT][8];
-    int pa[kMfmaQT];
-#pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) {
-        const int qi = min(q0 + 32 * qt + r, nQ - 1);
-        const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
-        const uint4 x = qp[0], y = qp[1];
-        const uint32_t qd[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-        pa[qt] = 0;
-#pragma unroll
-        for (int s = 0; s < 8; s++) {
-            bq[qt][s] = expand16((qd[s] >> (16 * half)) & 0xffffu);
-            bq[qt][s] = (bq[qt][s] << 8) - bq[qt][s];          // 1 -> 0xff: the B operand holds 0 / -1
-            pa[qt] += __popc(qd[s]);
-        }
-    }
-    uint32_t best[kMfmaQT], second[kMfmaQT];
-#pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) { best[qt] = 0xffffffffu; second[qt] = 0xffffffffu; }
-
-    // train row r of a tile: this wavefront needs the dwords of its own k-steps; wavefront 0 reads the whole
-    // descriptor for |b|
-    const uint32_t* tp = t + (size_t)b * t_stride * 8;
-    uint32_t mine[kMfmaSteps] = {};
-    uint4 x = make_uint4(0, 0, 0, 0), y = x;
-    auto fetch = [&](int j) {
-        const int ti = min(j + r, j1 - 1);
-        if (wave == 0) {
-            x = reinterpret_cast<const uint4*>(tp)[2 * ti];
-            y = reinterpret_cast<const uint4*>(tp)[2 * ti + 1];
-        } else {
-#pragma unroll
-            for (int k = 0; k < kMfmaSteps; k++) mine[k] = tp[8 * (size_t)ti + kMfmaSteps * wave + k];
-        }
-    };
-    if (j0 < j1) fetch(j0);
-    int buf = 0;
-    for (int j = j0; j < j1; j += 32, buf ^= 1) {
-        if (wave == 0) {
-            mine[0] = x.x;
-            if (kMfmaSteps > 1) mine[kMfmaSteps - 1] = x.y;
-            if (half == 0) {
-                const int pb = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
-                s_k[buf][r] = ((uint32_t)(pb + 256) << 22) | (uint32_t)(j + r);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < kMfmaSteps; k++)
-            s_a[buf][(kMfmaSteps * wave + k) * 64 + lane] = expand16((mine[k] >> (16 * half)) & 0xffffu);
-        if (j + 32 < j1) fetch(j + 32);
-        __syncthreads();
-        if (active) {
-            if (j + 32 <= j1) mfma_sweep<false>(s_a[buf], s_k[buf], lane, half, bq, 32, best, second);
-            else mfma_sweep<true>(s_a[buf], s_k[buf], lane, half, bq, j1 - j, best, second);
-        }
-    }
-    if (!active) return;
-
-    // the two halves of the wavefront saw different trains of the same query: merge, then restore |a|
-#pragma unroll
-    for (int qt = 0; qt < kMfmaQT; qt++) {
-        const uint32_t ob = __shfl_xor(best[qt], 32, 64), os = __shfl_xor(second[qt], 32, 64);
-        push_key(best[qt], second[qt], ob);
-        push_key(best[qt], second[qt], os);
-        const int qi = q0 + 32 * qt + r;
-        if (half != 0 || qi >= nQ) continue;
-        // field -> true distance: + |a| - 256; "no candidate" stays the sentinel of the scalar kernel
-        const uint32_t fix = (uint32_t)(pa[qt] - 256) << 22;
-        const uint32_t kb = best[qt] == 0xffffffffu ? kKeyNone : best[qt] + fix;
-        const uint32_t ks = second[qt] == 0xffffffffu ? kKeyNone : second[qt] + fix;
-        const size_t o = (size_t)b * q_stride + qi;
-        if (tsplit == 1) {
-            best_idx[o] = (kb >> 22) >= 256u ? -1 : (int32_t)(kb & 0x3FFFFFu);
-            best_dist[o] = (int32_t)(kb >> 22);
-            second_dist[o] = (int32_t)(ks >> 22);
-        } else {
-            uint32_t* p = partial + (((size_t)b * tsplit + blockIdx.y) * q_stride + qi) * 2;
-            p[0] = kb;
-            p[1] = ks;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// The same sweep on the block-scaled FP4 matrix instruction: v_mfma_scale_f32_32x32x64_f8f6f4 with both operands
-// e2m1 takes 64 bits of the descriptors per instruction at the cycles the i8 form needs for 32, so a 256-bit inner
-// product is four instructions instead of eight, an expanded fragment is half as large and a byte expands through
-// a 256-entry table in LDS.  A set bit becomes the nibble 0b0010 = 1.0 in the trains and 0b1010 = -1.0 in the
-// queries, and the queries' block scale is 2^13, so a common bit contributes -2 * 4096.  Which of a lane's 32
-// nibbles stands for which bit does not matter as long as trains and queries expand alike: the instruction pairs
-// equal positions.
+// Brute force on the matrix cores.  Hamming(a, b) = |a| + |b| - 2 <a, b> for bit vectors, and the 256-bit inner
+// products of 32 train x 32 query descriptors are one chain of four v_mfma_scale_f32_32x32x64_f8f6f4 with both
+// operands e2m1 (FP4): 64 bits of the descriptors per instruction, a bit expanded to a nibble through a 256-entry
+// table in LDS.  With the trains as the A operand and the queries as B, lane l of the 32x32 result holds query l & 31
+// against 16 trains (rows (reg & 3) + 8 * (reg >> 2) + 4 * (l >> 5)), so the (best, second) update is lane-local: two
+// vector instructions per pair instead of the ~19 of the xor/popcount form.  A wavefront keeps the expanded nibbles of
+// kMfmaQT * 32 queries in registers and streams the train tiles past them; key order, and therefore the tie rule
+// "smallest distance, then smallest index", is that of k_match_bruteforce.
+//
+// A set bit becomes the nibble 0b0010 = 1.0 in the trains and 0b1010 = -1.0 in the queries, and the queries' block
+// scale is 2^13, so a common bit contributes -2 * 4096.  Which of a lane's 32 nibbles stands for which bit does not
+// matter as long as trains and queries expand alike: the instruction pairs equal positions.
 //
 // The accumulator IS the key.  Row r of a tile starts (C operand, the same in every column) at
 //     1.5 * 2^23 + (|b_r| + 256) * 4096 + position of r in the current run of 4096 train descriptors,
 // all sums stay integers below 2^24 and so exact in f32, and the bit pattern of the result is
 //     0x4B400000 + (|b_r| + 256 - 2 <a, b_r>) * 4096 + position:
-// ordered like (distance, index) for one query, so the best two are kept by comparing accumulator registers as
-// they come, without a shift or an add per pair.  After every 4096 train descriptors the two survivors are
-// rewritten as keys on the index in the whole train set.
+// ordered like (distance, index) for one query (|a| is the same for every candidate of a query and is added at the
+// end), so the best two are kept by comparing accumulator registers as they come, without a shift or an add per pair.
+// After every 4096 train descriptors the two survivors are rewritten as keys on the index in the whole train set.
+// (The first matrix form, eight v_mfma_i32_32x32x32_i8 per tile on bits expanded to bytes with a shift-add per pair
+// for the key, took 1.5 times as long on long sweeps and 1.2-1.4 times on short ones.)
 // ---------------------------------------------------------------------------
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+constexpr int kMfmaQT = 2;              // query tiles (of 32) per wavefront
 typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v16f_t __attribute__((ext_vector_type(16)));
 constexpr int kFp4Waves = 4;                    // one k-step (64 bits) of the train tile per wavefront
-static_assert(kFp4Waves == kMfmaWaves, "the two sweeps share a launch grid");
 constexpr int kFp4RunBits = 12;                 // positions per run: 10 bits of distance field above them fill the mantissa below bit 22
 constexpr uint32_t kFp4Base = 0x4B400000u;      // 1.5 * 2^23 as a bit pattern
 
@@ -406,8 +240,9 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
     int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
     int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
 {
-    __shared__ v4i_t s_a[2][2][4 * 64];                         // expanded train fragments: [buffer][tile of the pair][k-step][lane]
-    __shared__ __align__(16) uint32_t s_c[3][64];               // start value (bit pattern) of every train row: [pair mod 3][row]
+    constexpr int NT = 4;                                       // tiles per barrier (1 / 2 / 4: 0.855 / 0.813 / 0.792 ms for 8 x 8000 x 100000)
+    __shared__ v4i_t s_a[2][NT][4 * 64];                        // expanded train fragments: [buffer][tile of the group][k-step][lane]
+    __shared__ __align__(16) uint32_t s_c[3][32 * NT];          // start value (bit pattern) of every train row: [group mod 3][row]
     __shared__ uint32_t s_lut[256];                             // byte -> eight e2m1 values (bit i -> nibble i = 1.0)
     const int b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
@@ -418,7 +253,7 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
         s_lut[threadIdx.x] = v;
     }
     constexpr uint32_t kRowBase = kFp4Base + (256u << kFp4RunBits);
-    if (threadIdx.x < 64) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;         // the first pair's rows: positions 0..63 of the first run
+    if (threadIdx.x < 32 * NT) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;    // the first group's rows: positions 0.. of the first run
     __syncthreads();
     const int nQ = nq ? min(nq[b], q_stride) : Q;
     const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
@@ -469,31 +304,36 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
         }
     };
 
-    // Two tiles per barrier (one: 4 % slower).  Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half
-    // of the row, and adds that dword's share of |b_r| to the row's start value, which a wavefront set up one pair of
-    // tiles ahead (three buffers: the pair being swept, the pair being built, and the one after it being set up).  Runs
+    // Train row r of a tile: wavefront w expands k-step w, i.e. dword 2 w + half
+    // of the row, and adds that dword's share of |b_r| to the row's start value, which a wavefront set up one group of
+    // tiles ahead (three buffers: the group being swept, the group being built, and the one after it being set up).  Runs
     // of 4096 positions start at j0.
     constexpr int kRunMask = (1 << kFp4RunBits) - 1;
     int buf = 0, cb = 0;
-    uint32_t mine1 = 0;
-    if (j0 + 32 < j1) mine1 = tp[8 * (size_t)min(j0 + 32 + r, j1 - 1)];
-    for (int j = j0; j < j1; j += 64, buf ^= 1) {
-        atomicAdd(&s_c[cb][r], (uint32_t)__popc(mine) << kFp4RunBits);
-        atomicAdd(&s_c[cb][32 + r], (uint32_t)__popc(mine1) << kFp4RunBits);
-        s_a[buf][0][wave * 64 + lane] = expand32_fp4(s_lut, mine);
-        s_a[buf][1][wave * 64 + lane] = expand32_fp4(s_lut, mine1);
+    uint32_t mn[NT];
+    mn[0] = mine;
+#pragma unroll
+    for (int k = 1; k < NT; k++) mn[k] = j0 + 32 * k < j1 ? tp[8 * (size_t)min(j0 + 32 * k + r, j1 - 1)] : 0u;
+    for (int j = j0; j < j1; j += 32 * NT, buf ^= 1) {
+#pragma unroll
+        for (int k = 0; k < NT; k++) {
+            atomicAdd(&s_c[cb][32 * k + r], (uint32_t)__popc(mn[k]) << kFp4RunBits);
+            s_a[buf][k][wave * 64 + lane] = expand32_fp4(s_lut, mn[k]);
+        }
         const int cn = cb == 2 ? 0 : cb + 1;
-        if (threadIdx.x < 64) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 64 - j0) & kRunMask) + (int)threadIdx.x);
-        if (j + 64 < j1) mine = tp[8 * (size_t)min(j + 64 + r, j1 - 1)];
-        if (j + 96 < j1) mine1 = tp[8 * (size_t)min(j + 96 + r, j1 - 1)];
+        if (threadIdx.x < 32 * NT) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 * NT - j0) & kRunMask) + (int)threadIdx.x);
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+            if (j + 32 * (NT + k) < j1) mn[k] = tp[8 * (size_t)min(j + 32 * (NT + k) + r, j1 - 1)];
         __syncthreads();
         if (active) {
             const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
-            if (j + 32 <= j1) fp4_sweep<QT, false>(s_a[buf][0], c_rows, lane, half, bq, 32, best, second);
-            else fp4_sweep<QT, true>(s_a[buf][0], c_rows, lane, half, bq, j1 - j, best, second);
-            if (j + 64 <= j1) fp4_sweep<QT, false>(s_a[buf][1], c_rows + 32, lane, half, bq, 32, best, second);
-            else if (j + 32 < j1) fp4_sweep<QT, true>(s_a[buf][1], c_rows + 32, lane, half, bq, j1 - j - 32, best, second);
-            if (((j + 64 - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
+#pragma unroll
+            for (int k = 0; k < NT; k++) {
+                if (j + 32 * (k + 1) <= j1) fp4_sweep<QT, false>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, 32, best, second);
+                else if (j + 32 * k < j1) fp4_sweep<QT, true>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, j1 - j - 32 * k, best, second);
+            }
+            if (((j + 32 * NT - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
         }
         cb = cn;
     }
@@ -542,25 +382,15 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
                              int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
                              int32_t* d_second_dist, hipStream_t s)
 {
-    // the matrix-core sweep pays from a few thousand pairs per query tile on; tiny problems keep the scalar form
-    static const bool no_mfma = getenv("ORBX_MATCH_NO_MFMA") != nullptr;
-    if (!no_mfma && T >= 64 && q_stride >= 32) {
-        const int per_wg = kMfmaWaves * 32 * kMfmaQT;
+    // the matrix-core sweep needs whole tiles to pay: tiny problems keep the scalar form.  ORBX_MATCH_FORM=scalar takes
+    // it for every size (read per call: tests compare the two forms).
+    const char* e_form = getenv("ORBX_MATCH_FORM");
+    const bool scalar = (e_form && e_form[0] == 's') || getenv("ORBX_MATCH_NO_MFMA") != nullptr;
+    if (!scalar && T >= 64 && q_stride >= 32) {
+        const int per_wg = kFp4Waves * 32 * kMfmaQT;
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
-        // The FP4 form has the cheaper sweep and the dearer start (a table in LDS, queries expanded through it): it
-        // takes over from a dozen tiles per workgroup on (measured: 313 train descriptors per workgroup 4 % faster, 391
-        // 10 %, 910 26 %; 257 a quarter slower).  ORBX_MATCH_FORM=i8|fp4 forces one (read per call: a test compares
-        // the two).
-        const int chunk = (T + tsplit - 1) / tsplit;
-        bool fp4 = chunk >= 384;
-        if (const char* e = getenv("ORBX_MATCH_FORM")) fp4 = e[0] == 'f' ? true : (e[0] == 'i' ? false : fp4);
-        if (!fp4) {
-            hipLaunchKernelGGL(k_match_bruteforce_mfma, grid, dim3(64 * kMfmaWaves), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride,
-                               d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
-        } else {
-            hipLaunchKernelGGL(k_match_bruteforce_fp4<kMfmaQT>, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T,
-                               t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
-        }
+        hipLaunchKernelGGL(k_match_bruteforce_fp4<kMfmaQT>, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T,
+                           t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
     } else {
         dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
         hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,
@@ -651,7 +481,7 @@ void launch_hamming_csr(const uint32_t* d_q, int Q, const uint32_t* d_t, const i
 
 // ---------------------------------------------------------------------------
 // Scratch for the entry point that allocates nothing (orbx_match_bruteforce_device_static): the
-// per-split (best, second) keys of k_match_bruteforce[_mfma] that k_match_merge combines.  Every GPU the
+// per-split (best, second) keys of k_match_bruteforce[_fp4] that k_match_merge combines.  Every GPU the
 // library runs on holds its own copy of this array, at its own address, until the process ends.
 // The name below is only a host-side handle: kernels get the address hipGetSymbolAddress reports
 // for the current device.

@@ -37,7 +37,7 @@ def test_descriptor_distance(matcher, oracle):
         assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
 
 
-FORMS = ["auto", "i8", "fp4"]     # the two matrix-core sweeps of the brute-force search, and the library's own choice
+FORMS = ["auto", "scalar"]     # the library's own choice (the matrix-core sweep from 64 train descriptors on) and the scalar sweep
 
 
 @pytest.fixture(params=FORMS)
@@ -99,8 +99,8 @@ def test_bruteforce_extreme_popcounts(matcher, oracle, form):
 
 
 def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
-    """A train set long enough that one workgroup sweeps more than 4096 descriptors (the FP4 form rewrites its
-    survivors as keys on the whole set at that period): both forms agree on every query, the oracle on a sample
+    """A train set long enough that one workgroup sweeps more than 4096 descriptors (the matrix form rewrites its
+    survivors as keys on the whole set at that period): it agrees with the scalar form on every query, the oracle on a sample
     of them; equal descriptors sit on both sides of the first period's end, so the tie goes across it."""
     rng = np.random.default_rng(5)
     Q, T = 16384, 150017
@@ -111,12 +111,12 @@ def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
     t[T - 1] = q[11]
     t[100000] = q[13] ^ np.uint8(1)            # one bit per byte off: distance 32, far below a random pair's
     res = {}
-    for f in ("i8", "fp4"):
+    for f in ("scalar", "auto"):
         monkeypatch.setenv("ORBX_MATCH_FORM", f)
         res[f] = matcher.match_bruteforce(q, t)
-    for a, b in zip(res["i8"], res["fp4"]):
+    for a, b in zip(res["scalar"], res["auto"]):
         assert np.array_equal(a, b)
-    bi, bd, sd = res["fp4"]
+    bi, bd, sd = res["auto"]
     assert bi[7] == 4095 and bd[7] == 0 and sd[7] == 0
     assert bi[9] == 4096 + 4095 and sd[9] == 0
     assert bi[11] == T - 1 and bd[11] == 0
@@ -128,7 +128,7 @@ def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
 
 def test_bruteforce_largest_train_set(matcher, oracle, monkeypatch):
     """2^22 - 1 train descriptors, the most the 22-bit index field of a key holds: the last index is found, in
-    every matrix form, and one more descriptor is refused."""
+    both forms, and one more descriptor is refused."""
     from orb_slam_amd import OrbxError
     rng = np.random.default_rng(17)
     Q, T = 40, (1 << 22) - 1
@@ -138,7 +138,7 @@ def test_bruteforce_largest_train_set(matcher, oracle, monkeypatch):
     t[T - 2] = q[4] ^ np.uint8(128)
     oi, od, os_ = oracle.match_bruteforce(q, t)
     assert oi[3] == T - 1 and od[3] == 0
-    for f in ("i8", "fp4"):
+    for f in ("auto", "scalar"):
         monkeypatch.setenv("ORBX_MATCH_FORM", f)
         bi, bd, sd = matcher.match_bruteforce(q, t)
         assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_), f

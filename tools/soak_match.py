@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity soak of the brute-force Hamming search: random query / train counts, batches with ragged
-counts, a train set shared by the whole batch, descriptors with planted duplicates and near-duplicates, every
-form of the sweep (scalar, i8 matrix, FP4 matrix, the library's own choice) against the CPU oracle; best index,
-best distance and second distance must agree exactly.
+counts, a train set shared by the whole batch, descriptors with planted duplicates and near-duplicates, both forms
+of the sweep (the library's own choice: FP4 matrix instructions from 64 train descriptors on; the scalar sweep for
+every size) against the CPU oracle; best index, best distance and second distance must agree exactly.
 Usage: python tools/soak_match.py [n_cases] [seed]"""
 import os
 import sys
@@ -57,12 +57,10 @@ def main():
         dq, dt = torch.from_numpy(q).to(dev), torch.from_numpy(t).to(dev)
         dnq, dnt = torch.from_numpy(nq).to(dev), torch.from_numpy(nt).to(dev)
         ref = [orc.match_bruteforce(q[b, :nq[b]], t[0 if shared else b, :nt[b]]) for b in range(nb)]
-        for form in ("auto", "i8", "fp4", "scalar"):
+        for form in ("auto", "scalar"):
             os.environ.pop("ORBX_MATCH_FORM", None)
-            if form in ("i8", "fp4"):
+            if form == "scalar":
                 os.environ["ORBX_MATCH_FORM"] = form
-            if form == "scalar" and (qs >= 32 and ts >= 64):
-                continue                        # the scalar form is the library's choice for tiny problems only
             outs = [torch.full((nb, qs), -7, dtype=torch.int32, device=dev) for _ in range(3)]
             m.match_bruteforce_device(dq, qs, qs, dnq, dt, ts, 0 if shared else ts, dnt, nb, *outs)
             torch.cuda.synchronize()

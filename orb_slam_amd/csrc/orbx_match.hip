@@ -184,9 +184,8 @@ __device__ __forceinline__ v4i_t expand32_fp4(const uint32_t* __restrict__ lut, 
     return r;
 }
 
-// c_rows: the start values of the tile's 32 rows.  Every accumulator reads them through an offset the compiler cannot
-// see through: one shared read would be kept in registers of its own as the C operand of a first instruction that
-// writes other registers, sixteen more registers per tile.
+// c_rows: the start values of the tile's 32 rows (one set of reads serves every accumulator: the first matrix
+// instruction of the second accumulator takes the first one's start registers as its C operand)
 template <int QT, bool kPartial>
 __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, const float* __restrict__ c_rows, int lane, int half,
                                           const v4i_t (&bq)[QT][4], int valid_rows, uint32_t (&best)[QT],
@@ -197,8 +196,7 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
     v16f_t acc[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; qt++) {
-        int row0 = 4 * half;
-        asm("" : "+v"(row0));
+        const int row0 = 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; g++) {                           // register 4 g + i holds row 8 g + 4 half + i
             const float4 c = *reinterpret_cast<const float4*>(c_rows + row0 + 8 * g);

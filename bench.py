@@ -546,7 +546,9 @@ def main():
         res = {}
         for name, fn, pairs, nq in (
                 ("stereo_128x1000x1000", lambda: m.match_bruteforce_device(dq, Q, Q, None, dt, Q, Q, None, nb, *outs), nb * Q * Q, nb * Q),
-                ("map_8000x100000", lambda: m.match_bruteforce_device(dq2, Q2, Q2, None, dt2, T2, T2, None, 1, *outs2), Q2 * T2, Q2)):
+                ("map_8000x100000", lambda: m.match_bruteforce_device(dq2, Q2, Q2, None, dt2, T2, T2, None, 1, *outs2), Q2 * T2, Q2),
+                # one ordinary frame's features against the same map (the first 1000 queries of the set above)
+                ("frame_1000x100000", lambda: m.match_bruteforce_device(dq2, Q, Q, None, dt2, T2, T2, None, 1, *outs2), Q * T2, Q)):
             settle(fn, args.settle_ms / 2)
             for _ in range(3):
                 fn()

@@ -274,13 +274,12 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
         const int qi = min(q0 + 32 * qt + r, nQ - 1);
         const uint4* qp = reinterpret_cast<const uint4*>(q + ((size_t)b * q_stride + qi) * 8);
         const uint4 x = qp[0], y = qp[1];
-        const uint32_t qd[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
-        pa[qt] = 0;
-#pragma unroll
-        for (int s = 0; s < 8; s++) pa[qt] += __popc(qd[s]);
+        pa[qt] = __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) + __popc(y.z) + __popc(y.w);
+        // (selects written out: an array indexed by `half` would live in scratch memory)
+        const uint32_t mine4[4] = {half ? x.y : x.x, half ? x.w : x.z, half ? y.y : y.x, half ? y.w : y.z};
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            bq[qt][s] = expand32_fp4(s_lut, half ? qd[2 * s + 1] : qd[2 * s]);
+            bq[qt][s] = expand32_fp4(s_lut, mine4[s]);
             bq[qt][s] = bq[qt][s] | (bq[qt][s] << 2);          // 0b0010 -> 0b1010: the B operand holds 0 / -1.0
         }
     }

@@ -157,10 +157,13 @@ int orbx_match_bruteforce_device(orbx_ctx *ctx, const uint32_t *d_q, int Q, int 
  * harnesses that forbid hipMalloc.  orbx_match_bruteforce_device keeps the per-split partial
  * results of a large search in a buffer it allocates (and grows) on demand; this entry point keeps
  * them in a static device array of 4 MiB that every GPU the library runs on holds until the
- * process ends, and calls no hipMalloc / hipFree.  Problems whose partial results need more
- * (nbatch * tsplit * q_stride * 8 bytes; 8000 x 100 000 needs 3.9 MiB, 128 x 1000 x 1000 needs 2.9 MiB,
- * 300 x 1000 x 1000 would need 4.6 MiB)
- * are rejected with ORBX_ERR_CAPACITY and a message naming both sizes.  All calls on one GPU share
+ * process ends, and calls no hipMalloc / hipFree.  The partial results take
+ * nbatch * tsplit * q_stride * 8 bytes (8000 x 100 000 in 64 splits: 3.9 MiB; 128 x 1000 x 1000 in 2: 2.0 MiB);
+ * when the split count orbx_match_bruteforce_device would choose does not fit (8 x 8000 queries against
+ * 100 000: 16 splits, 7.8 MiB), this entry point takes as many splits as fit (8), down to a single
+ * split, which needs no scratch at all: the results are the same, and no problem is refused for
+ * the scratch.  The limits of orbx_match_bruteforce_device apply (a train set of 2^22 descriptors
+ * or more is rejected with ORBX_ERR_UNSUPPORTED).  All calls on one GPU share
  * that GPU's array: calls that overlap in time on one GPU (different streams or contexts) race;
  * calls ordered on one stream do not, and nothing carries over between calls. */
 int orbx_match_bruteforce_device_static(orbx_ctx *ctx, const uint32_t *d_q, int Q, int q_stride, const int32_t *d_nq,

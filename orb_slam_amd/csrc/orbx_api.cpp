@@ -1030,14 +1030,12 @@ int orbx_match_bruteforce_device_static(orbx_ctx* c, const uint32_t* d_q, int Q,
     if (q_stride == 0) return ORBX_OK;
     HIPCHECK(c, hipSetDevice(c->device));
     if (!c->static_scratch) return fail(c, ORBX_ERR_HIP, "the static scratch array of this device could not be located at orbx_create");
-    const int tsplit = match_bruteforce_tsplit(q_stride, T, nbatch);
-    const size_t need = tsplit > 1 ? (size_t)nbatch * tsplit * q_stride * 8 : 0;
-    if (need > kMatchStaticScratchBytes) {
-        c->err = "problem needs " + std::to_string(need) + " bytes of scratch; the static scratch of "
-                 "orbx_match_bruteforce_device_static holds " + std::to_string(kMatchStaticScratchBytes) +
-                 " (use orbx_match_bruteforce_device, or fewer batches per call)";
-        return ORBX_ERR_CAPACITY;
-    }
+    // The preferred number of splits of the train set, or as many as the static scratch holds partial results for
+    // (nbatch * tsplit * q_stride * 8 bytes); a single split needs no scratch at all, so no size is refused for it.
+    int tsplit = match_bruteforce_tsplit(q_stride, T, nbatch);
+    const size_t per_split = (size_t)nbatch * (size_t)q_stride * 8;
+    if (tsplit > 1 && per_split * (size_t)tsplit > kMatchStaticScratchBytes)
+        tsplit = (int)std::max<size_t>(1, kMatchStaticScratchBytes / per_split);
     // every slot k_match_merge reads is written by this call's sweep first: nothing to clear
     launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->static_scratch,
                             d_best_idx, d_best_dist, d_second_dist, c->stream);

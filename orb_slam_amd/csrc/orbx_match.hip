@@ -363,9 +363,15 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
 
 int match_bruteforce_tsplit(int Q, int T, int nbatch)
 {
-    // enough workgroups to fill 256 CUs a few times over, chunks of >= 256 train descriptors
+    // chunks of >= 256 train descriptors
     long qblocks = (long)((Q + 255) / 256) * nbatch;
-    long want = (2048 + qblocks - 1) / qblocks;
+    // Workgroups wanted: one round on the chip's 1024 workgroup slots for small problems (start and end of a workgroup
+    // weigh as much as its sweep), two or four rounds for large ones (the rounds cover each other's starts and ends).
+    // Measured, 1024 / 2048 / 4096: 8 x 8000 x 100000 0.817 / 0.782 / 0.775 ms, 8000 x 100000 0.110 / 0.110 / 0.114,
+    // 128 x 1000 x 1000 0.0246 / 0.0264 / 0.0262, 1000 x 100000 0.0257 / 0.0290 / 0.0290.
+    const long tiles = qblocks * ((T + 31) / 32);            // tiles of 256 queries x 32 train descriptors
+    const long target = tiles >= 200 * 1024 ? 4096 : (tiles >= 60 * 1024 ? 2048 : 1024);
+    long want = (target + qblocks - 1) / qblocks;
     long maxsplit = T / 256;
     if (maxsplit < 1) maxsplit = 1;
     long s = want < maxsplit ? want : maxsplit;

@@ -49,12 +49,22 @@ def test_static_scratch_entry_point_matches_allocating_one():
     got, ref = _both(m, ex, torch, qb, tb, nb=6)
     for g, r in zip(got, ref):
         assert np.array_equal(g, r)
-    # beyond the static scratch: a clear refusal, nothing launched
+    # fourth: more partial results than the static scratch holds at the preferred split count (16 batches of 4000
+    # queries, each train set in 16 splits: 7.8 MiB): fewer splits, the same results
+    rng = np.random.default_rng(4)
+    qc = rng.integers(0, 256, (16, 4000, 32), dtype=np.uint8)
+    tc = rng.integers(0, 256, (16, 40000, 32), dtype=np.uint8)
+    tc[3, 39999] = qc[3, 17]
+    got, ref = _both(m, ex, torch, qc, tc, nb=16)
+    for g, r in zip(got, ref):
+        assert np.array_equal(g, r)
+    assert got[0][3, 17] == 39999 and got[1][3, 17] == 0
+    # a train set beyond the 22-bit index field: a clear refusal, nothing launched
     dev = torch.device("cuda", 0)
-    big_q = torch.zeros((300, 1000, 32), dtype=torch.uint8, device=dev)
-    big_t = torch.zeros((300, 1000, 32), dtype=torch.uint8, device=dev)
-    outs = [torch.zeros((300, 1000), dtype=torch.int32, device=dev) for _ in range(3)]
+    big_q = torch.zeros((1, 64, 32), dtype=torch.uint8, device=dev)
+    big_t = torch.zeros((1, 1 << 22, 32), dtype=torch.uint8, device=dev)
+    outs = [torch.zeros((1, 64), dtype=torch.int32, device=dev) for _ in range(3)]
     with pytest.raises(OrbxError) as ei:
-        m.match_bruteforce_device_static(big_q, 1000, 1000, None, big_t, 1000, 1000, None, 300, *outs)
-    assert ei.value.code == -4 and "static scratch" in str(ei.value)
+        m.match_bruteforce_device_static(big_q, 64, 64, None, big_t, 1 << 22, 1 << 22, None, 1, *outs)
+    assert ei.value.code == -5 and "2^22" in str(ei.value)
     ex.close()

@@ -292,6 +292,41 @@ int orbx_grid_search_device(orbx_ctx *ctx, const orbx_keypoint *d_kps, const uin
                             int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist,
                             int32_t *d_best_lvl, int32_t *d_second_lvl, int32_t *d_ncand);
 
+/* --- searches whose queries exclude what earlier queries claimed ------------------------ */
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize),
+ * src/ORBmatcher.cc:520-633.  k1 / d1 = F1.mvKeysUn / F1.mDescriptors (n1 rows), k2 / d2 = F2's;
+ * min_x .. inv_h = F2's mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv;
+ * prev_matched_xy = vbPrevMatched as n1 (x, y) pairs, in/out (:628-630); nnratio / check_orientation =
+ * the matcher's mfNNratio / mbCheckOrientation (include/ORBmatcher.h).  matches12[n1] = vnMatches12,
+ * *nmatches = the return value.  The device forms F2.GetFeaturesInArea(...) (:540) for every level-0
+ * keypoint of F1 with the distance of every candidate; the greedy part -- a candidate already held with
+ * a distance <= ours is skipped (:559-560), a better claim un-matches the previous holder (:578-582),
+ * the rotation histogram and ComputeThreeMaxima (:588-625) -- is walked in query order on the host. */
+int orbx_search_for_initialization(orbx_ctx *ctx, const orbx_keypoint *k1, const uint32_t *d1, int n1,
+                                   const orbx_keypoint *k2, const uint32_t *d2, int n2,
+                                   float min_x, float min_y, float inv_w, float inv_h,
+                                   float *prev_matched_xy, int window_size, float nnratio, int check_orientation,
+                                   int32_t *matches12, int *nmatches);
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th),
+ * src/ORBmatcher.cc:155-241, with the MapPoint members it reads as arrays of M entries:
+ * mbTrackInView, isBad() (NULL: none is bad), mTrackProjX, mTrackProjY, mTrackProjXR (may be NULL when
+ * u_right is), mnTrackScaleLevel, mTrackViewCos, GetDescriptor(), Observations().
+ * Frame: kps = mvKeysUn, desc = mDescriptors, u_right = mvuRight (NULL: monocular), the grid constants;
+ * mvScaleFactors are the context's.  In/out arrays of N entries:
+ *   frame_obs    Observations() of F.mvpMapPoints[idx], -1 where that pointer is NULL (the exclusion
+ *                test :197-199); an accepted match stores the map point's own count;
+ *   frame_match  index into the M map points of what this call assigned to F.mvpMapPoints[idx] (:233),
+ *                untouched elsewhere -- initialise to -1;
+ *   match_score  F.mvpMatchScore (:235).
+ * *nmatches = the return value. */
+int orbx_search_by_projection(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                              float min_x, float min_y, float inv_w, float inv_h,
+                              const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                              const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                              const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                              const int32_t *mp_observations, int M, float th, float nnratio,
+                              int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *nmatches);
+
 /* --- keypoint undistortion --------------------------------------------------- */
 /* Frame::UndistortKeyPoints / UndistortKeyPointsStereo, src/Frame.cc:745-852: the keypoint
  * coordinates go through cv::undistortPoints(pts, K, dist, R, P) (fisheye = 0) or

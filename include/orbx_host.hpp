@@ -216,6 +216,85 @@ private:
     }
 };
 
+// The grid constants of a Frame (src/Frame.cc:129-135): mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv
+struct FrameGrid {
+    float mnMinX = 0, mnMinY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+};
+
+// What ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) reads of each map point
+// (src/ORBmatcher.cc:161-184), as parallel arrays of one length
+struct MapPointsInView {
+    std::vector<uint8_t> mbTrackInView, isBad;
+    std::vector<float> mTrackProjX, mTrackProjY, mTrackProjXR, mTrackViewCos;
+    std::vector<int32_t> mnTrackScaleLevel, Observations;
+    std::vector<uint8_t> descriptors;     // 32 bytes per map point (GetDescriptor())
+};
+
+// The searches of ORB_SLAM2::ORBmatcher whose queries exclude what earlier queries claimed, with the
+// reference's constructor arguments (include/ORBmatcher.h: ORBmatcher(float nnratio = 0.6, bool checkOri = true)).
+// Candidate lists and distances come from the extractor's device; the sequential part runs inside the library.
+class ORBmatcher {
+public:
+    static constexpr int TH_LOW = 50, TH_HIGH = 100, HISTO_LENGTH = 30;   // src/ORBmatcher.cc:37-39
+    explicit ORBmatcher(ORBextractor& ex, float nnratio = 0.6f, bool checkOri = true)
+        : ex_(ex), mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+
+    // SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize), src/ORBmatcher.cc:520-633.
+    // keys / descriptors = mvKeysUn / mDescriptors of the two frames, grid2 = F2's; vbPrevMatched holds (x, y) per
+    // keypoint of F1 and is updated in place; returns nmatches.
+    int SearchForInitialization(const std::vector<orbx_keypoint>& keysUn1, const uint8_t* desc1,
+                                const std::vector<orbx_keypoint>& keysUn2, const uint8_t* desc2, const FrameGrid& grid2,
+                                std::vector<float>& vbPrevMatched, std::vector<int32_t>& vnMatches12, int windowSize = 10)
+    {
+        if (vbPrevMatched.size() != 2 * keysUn1.size()) throw std::invalid_argument("vbPrevMatched needs (x, y) per keypoint of F1");
+        vnMatches12.assign(keysUn1.size(), -1);
+        int nmatches = 0;
+        check(orbx_search_for_initialization(ex_.context(), keysUn1.data(), reinterpret_cast<const uint32_t*>(desc1),
+                                             (int)keysUn1.size(), keysUn2.data(), reinterpret_cast<const uint32_t*>(desc2),
+                                             (int)keysUn2.size(), grid2.mnMinX, grid2.mnMinY, grid2.mfGridElementWidthInv,
+                                             grid2.mfGridElementHeightInv, vbPrevMatched.data(), windowSize, mfNNratio,
+                                             mbCheckOrientation ? 1 : 0, vnMatches12.data(), &nmatches));
+        return nmatches;
+    }
+
+    // SearchByProjection(F, vpMapPoints, th), src/ORBmatcher.cc:155-241.  frame_obs[i] = Observations() of
+    // F.mvpMapPoints[i] or -1 for a null pointer (in/out); frame_match[i] = index of the map point this call assigned
+    // to keypoint i (set to -1 beforehand by the caller); mvpMatchScore as in the reference.  Returns nmatches.
+    int SearchByProjection(const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc, const std::vector<float>* mvuRight,
+                           const FrameGrid& grid, const MapPointsInView& mp, float th, std::vector<int32_t>& frame_obs,
+                           std::vector<int32_t>& frame_match, std::vector<int32_t>& mvpMatchScore)
+    {
+        const size_t N = keysUn.size(), M = mp.mbTrackInView.size();
+        if (frame_obs.size() != N || frame_match.size() != N || mvpMatchScore.size() != N ||
+            mp.mTrackProjX.size() != M || mp.mTrackProjY.size() != M || mp.mnTrackScaleLevel.size() != M ||
+            mp.mTrackViewCos.size() != M || mp.Observations.size() != M || mp.descriptors.size() != 32 * M ||
+            (mvuRight && (mvuRight->size() != N || mp.mTrackProjXR.size() != M)) || (!mp.isBad.empty() && mp.isBad.size() != M))
+            throw std::invalid_argument("array lengths do not agree");
+        int nmatches = 0;
+        check(orbx_search_by_projection(ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc),
+                                        mvuRight ? mvuRight->data() : nullptr, (int)N, grid.mnMinX, grid.mnMinY,
+                                        grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, mp.mbTrackInView.data(),
+                                        mp.isBad.empty() ? nullptr : mp.isBad.data(), mp.mTrackProjX.data(),
+                                        mp.mTrackProjY.data(), mp.mTrackProjXR.empty() ? nullptr : mp.mTrackProjXR.data(),
+                                        mp.mnTrackScaleLevel.data(), mp.mTrackViewCos.data(),
+                                        reinterpret_cast<const uint32_t*>(mp.descriptors.data()), mp.Observations.data(),
+                                        (int)M, th, mfNNratio, frame_obs.data(), frame_match.data(), mvpMatchScore.data(),
+                                        &nmatches));
+        return nmatches;
+    }
+
+private:
+    void check(int rc)
+    {
+        if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ex_.context()));
+    }
+    ORBextractor& ex_;
+
+public:
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+
 // ORBmatcher::DescriptorDistance (include/ORBmatcher.h:48) on raw 32-byte rows
 inline int DescriptorDistance(const uint8_t* a, const uint8_t* b)
 {

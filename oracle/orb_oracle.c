@@ -1720,3 +1720,184 @@ void oo_undistort_points(const float *xy_in, int n, const double K[9], const dou
         }
     }
 }
+
+/* ------------------------------------------------------------------------- *
+ * Search routines with sequential exclusion: the result of query k depends on
+ * what queries 0..k-1 claimed.  Restated on plain arrays; the candidate list of
+ * a query (Frame::GetFeaturesInArea) is a pure function of the frame, so all
+ * lists are formed first and the loops below walk them exactly as written.
+ * ------------------------------------------------------------------------- */
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1723-1764 (histo[i].size() given as sizes[i]) */
+void oo_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            *ind3 = *ind2; *ind2 = i;
+        } else if (s > max3) {
+            max3 = s; *ind3 = i;
+        }
+    }
+    if (max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+#define OO_TH_LOW 50          /* src/ORBmatcher.cc:37 */
+#define OO_TH_HIGH 100        /* :38 */
+#define OO_HISTO_LENGTH 30    /* :39 */
+
+/* ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:520-633 */
+int oo_search_for_initialization(const oo_keypoint *k1, const uint32_t *d1, int n1,
+                                 const oo_keypoint *k2, const uint32_t *d2, int n2,
+                                 float minX, float minY, float invW, float invH,
+                                 float *prev_matched_xy, int windowSize, float nnratio, int check_orientation,
+                                 int32_t *matches12)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                      /* :523 */
+    int *rotHist[OO_HISTO_LENGTH], rotN[OO_HISTO_LENGTH];                 /* :525-527 */
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) { rotHist[i] = (int *)malloc(sizeof(int) * (size_t)(n1 > 0 ? n1 : 1)); rotN[i] = 0; }
+    const float factor = 1.0f / OO_HISTO_LENGTH;                          /* :528 */
+    int *vMatchedDistance = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    int *vnMatches21 = (int *)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+    for (int i = 0; i < n2; i++) { vMatchedDistance[i] = INT32_MAX; vnMatches21[i] = -1; }   /* :530-531 */
+
+    /* F2.GetFeaturesInArea(vbPrevMatched[i1].x, .y, windowSize, level1, level1) for every i1 (:540) */
+    float *qx = (float *)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(float)), *qy = (float *)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(float));
+    float *qr = (float *)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(float));
+    int32_t *ql = (int32_t *)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(int32_t));
+    int32_t *off = (int32_t *)calloc(((size_t)n1 + 1), sizeof(int32_t));
+    for (int i = 0; i < n1; i++) {
+        qx[i] = prev_matched_xy[2 * i]; qy[i] = prev_matched_xy[2 * i + 1];
+        qr[i] = (float)windowSize; ql[i] = k1[i].octave;
+    }
+    const int total = oo_features_in_area(k2, n2, minX, minY, invW, invH, qx, qy, qr, ql, ql, n1, off, NULL, 0);
+    int32_t *idx = (int32_t *)calloc((size_t)(total > 0 ? total : 1), sizeof(int32_t));
+    oo_features_in_area(k2, n2, minX, minY, invW, invH, qx, qy, qr, ql, ql, n1, off, idx, total);
+
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int level1 = k1[i1].octave;
+        if (level1 > 0) continue;                                          /* :537-538 */
+        if (off[i1 + 1] == off[i1]) continue;                              /* :542-543 */
+        int bestDist = INT32_MAX, bestDist2 = INT32_MAX, bestIdx2 = -1;
+        for (int k = off[i1]; k < off[i1 + 1]; k++) {
+            const int i2 = idx[k];
+            const int dist = oo_hamming(d1 + 8 * (size_t)i1, d2 + 8 * (size_t)i2);
+            if (vMatchedDistance[i2] <= dist) continue;                    /* :559-560 */
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= OO_TH_LOW) {                                       /* :574 */
+            if (bestDist < (float)bestDist2 * nnratio) {                   /* :576 */
+                if (vnMatches21[bestIdx2] >= 0) {                          /* :578-582 */
+                    matches12[vnMatches21[bestIdx2]] = -1;
+                    nmatches--;
+                }
+                matches12[i1] = bestIdx2;
+                vnMatches21[bestIdx2] = i1;
+                vMatchedDistance[bestIdx2] = bestDist;
+                nmatches++;
+                if (check_orientation) {                                   /* :588-598 */
+                    float rot = k1[i1].angle - k2[bestIdx2].angle;
+                    if (rot < 0.0) rot += 360.0f;
+                    int bin = (int)roundf(rot * factor);
+                    if (bin == OO_HISTO_LENGTH) bin = 0;
+                    rotHist[bin][rotN[bin]++] = i1;
+                }
+            }
+        }
+    }
+    if (check_orientation) {                                               /* :603-625 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(rotN, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < rotN[i]; j++) {
+                const int idx1 = rotHist[i][j];
+                if (matches12[idx1] >= 0) { matches12[idx1] = -1; nmatches--; }
+            }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                        /* :628-630 */
+        if (matches12[i1] >= 0) {
+            prev_matched_xy[2 * i1] = k2[matches12[i1]].x;
+            prev_matched_xy[2 * i1 + 1] = k2[matches12[i1]].y;
+        }
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) free(rotHist[i]);
+    free(vMatchedDistance); free(vnMatches21); free(qx); free(qy); free(qr); free(ql); free(off); free(idx);
+    return nmatches;
+}
+
+/* ORBmatcher::RadiusByViewingCos, src/ORBmatcher.cc:243-249 (float compared with the double 0.998) */
+static float radius_by_viewing_cos(float viewCos) { return viewCos > 0.998 ? 2.5f : 4.0f; }
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th),
+ * src/ORBmatcher.cc:155-241 */
+int oo_search_by_projection(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                            const float *scale_factors, float minX, float minY, float invW, float invH,
+                            const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                            const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                            const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                            const int32_t *mp_observations, int M, float th, float nnratio,
+                            int32_t *frame_obs, int32_t *frame_match, int32_t *match_score)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;                                         /* :159 */
+    const size_t m1 = (size_t)(M > 0 ? M : 1);
+    float *qx = (float *)calloc(m1, sizeof(float)), *qy = (float *)calloc(m1, sizeof(float)), *qr = (float *)calloc(m1, sizeof(float));
+    float *rr = (float *)calloc(m1, sizeof(float));
+    int32_t *qmin = (int32_t *)calloc(m1, sizeof(int32_t)), *qmax = (int32_t *)calloc(m1, sizeof(int32_t));
+    int32_t *off = (int32_t *)calloc(((size_t)M + 1), sizeof(int32_t));
+    for (int i = 0; i < M; i++) {
+        float r = radius_by_viewing_cos(mp_view_cos[i]);                   /* :173 */
+        if (bFactor) r *= th;                                              /* :175-176 */
+        rr[i] = r;
+        const int lvl = mp_level[i];
+        /* :178-179; a map point the loop skips (:164-168) asks for nothing */
+        const int skip = !mp_track_in_view[i] || mp_is_bad[i];
+        qx[i] = mp_proj_x[i]; qy[i] = mp_proj_y[i];
+        qr[i] = skip ? -1.0f : r * scale_factors[lvl];
+        qmin[i] = lvl - 1; qmax[i] = lvl;
+    }
+    const int total = oo_features_in_area(kps, N, minX, minY, invW, invH, qx, qy, qr, qmin, qmax, M, off, NULL, 0);
+    int32_t *idxs = (int32_t *)calloc((size_t)(total > 0 ? total : 1), sizeof(int32_t));
+    oo_features_in_area(kps, N, minX, minY, invW, invH, qx, qy, qr, qmin, qmax, M, off, idxs, total);
+
+    for (int iMP = 0; iMP < M; iMP++) {
+        if (!mp_track_in_view[iMP]) continue;                              /* :164-165 */
+        if (mp_is_bad[iMP]) continue;                                      /* :167-168 */
+        const int nPredictedLevel = mp_level[iMP];
+        const float r = rr[iMP];
+        if (off[iMP + 1] == off[iMP]) continue;                            /* :181-182 */
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = off[iMP]; k < off[iMP + 1]; k++) {
+            const int idx = idxs[k];
+            if (frame_obs[idx] > 0) continue;                              /* :197-199: a map point with observations */
+            if (u_right && u_right[idx] > 0) {                             /* :201-206 */
+                const float er = fabsf(mp_proj_xr[iMP] - u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = oo_hamming(mp_desc + 8 * (size_t)iMP, desc + 8 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= OO_TH_HIGH) {                                      /* :228 */
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;   /* :230-231 */
+            frame_match[bestIdx] = iMP;                                    /* :233 */
+            frame_obs[bestIdx] = mp_observations[iMP];
+            match_score[bestIdx] = bestDist;                               /* :235 */
+            nmatches++;
+        }
+    }
+    free(qx); free(qy); free(qr); free(rr); free(qmin); free(qmax); free(off); free(idxs);
+    return nmatches;
+}

@@ -212,6 +212,39 @@ int oo_features_in_area(const oo_keypoint *kps, int n, float minX, float minY, f
                         const float *qx, const float *qy, const float *qr, const int32_t *qmin,
                         const int32_t *qmax, int Q, int32_t *cand_off, int32_t *cand_idx, int cap);
 
+/* ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1723-1764; sizes[i] = histo[i].size().
+ * ind1..3 must be initialised by the caller (the reference passes -1). */
+void oo_three_maxima(const int *sizes, int L, int *ind1, int *ind2, int *ind3);
+
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize),
+ * src/ORBmatcher.cc:520-633, on plain arrays: k1/d1 = F1.mvKeysUn / mDescriptors, k2/d2 = F2's,
+ * minX..invH = F2's grid constants (mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv),
+ * prev_matched_xy = vbPrevMatched (n1 x 2 floats, updated in place as :628-630 do),
+ * nnratio / check_orientation = the matcher's mfNNratio / mbCheckOrientation.
+ * matches12[n1] = vnMatches12.  Returns nmatches. */
+int oo_search_for_initialization(const oo_keypoint *k1, const uint32_t *d1, int n1,
+                                 const oo_keypoint *k2, const uint32_t *d2, int n2,
+                                 float minX, float minY, float invW, float invH,
+                                 float *prev_matched_xy, int windowSize, float nnratio, int check_orientation,
+                                 int32_t *matches12);
+
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*> &vpMapPoints, const float th),
+ * src/ORBmatcher.cc:155-241, on plain arrays.  Frame: kps = mvKeysUn, desc = mDescriptors,
+ * u_right = mvuRight (NULL: monocular, every entry -1), scale_factors = mvScaleFactors, grid constants.
+ * Map point i: mbTrackInView, isBad(), mTrackProjX / Y / XR, mnTrackScaleLevel, mTrackViewCos,
+ * GetDescriptor(), Observations().
+ * frame_obs[N] (in/out): Observations() of F.mvpMapPoints[idx], -1 where that pointer is NULL; an
+ * accepted match stores the map point's own count, as assigning the pointer does (:233).
+ * frame_match[N] (in/out): index of the map point assigned to F.mvpMapPoints[idx] by this call
+ * (untouched elsewhere); match_score[N] (in/out): F.mvpMatchScore.  Returns nmatches. */
+int oo_search_by_projection(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                            const float *scale_factors, float minX, float minY, float invW, float invH,
+                            const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                            const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                            const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                            const int32_t *mp_observations, int M, float th, float nnratio,
+                            int32_t *frame_obs, int32_t *frame_match, int32_t *match_score);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -169,9 +170,14 @@ void harvest(orbx_ctx* c, EventSet& es)
     es.pending = false;
 }
 
+void drop_graph(orbx_ctx* c);
+
+// A recorded launch sequence (run_small_batch) holds the addresses of the geometry tables and of every per-batch
+// buffer: whoever frees or re-sizes one of them drops the recording, whatever entry point the change came through.
 int ensure_geometry(orbx_ctx* c, int w, int h)
 {
     if (c->gw == w && c->gh == h) return ORBX_OK;
+    drop_graph(c);
     FrameGeom g;
     ResizeTables rt;
     std::vector<XTab>& xt = rt.xtab;
@@ -215,6 +221,7 @@ int ensure_frames(orbx_ctx* c, int nframes)
     const FrameGeom& g = c->g;
     const size_t n = (size_t)nframes;
     HIPCHECK(c, hipStreamSynchronize(c->stream));
+    drop_graph(c);
     HIPCHECK(c, c->pyr.ensure(n * g.pyr_frame_bytes + 256));
     HIPCHECK(c, c->blur.ensure(n * g.pyr_frame_bytes + 256));
     HIPCHECK(c, c->cell_cand.ensure((n * g.cand_per_frame + 64) * 4));
@@ -321,6 +328,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     if (c->count_levels.n > 0) {
         const size_t need_bytes = (size_t)nframes * c->count_levels.n * c->count_levels.stride;
         if (need_bytes <= ((size_t)1 << 30)) {
+            if (need_bytes > c->qt_counts.bytes) drop_graph(c);
             HIPCHECK(c, c->qt_counts.ensure(need_bytes));
             cl = &c->count_levels;
         }
@@ -1532,6 +1540,229 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
     HIPCHECK(c, hipGetLastError());
     HIPCHECK(c, d2h(c, cand_idx, c->gq[11].p, (size_t)sum * 4));
     HIPCHECK(c, finish(c));
+    return ORBX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Searches with sequential exclusion (src/ORBmatcher.cc:155-241, :520-633): a query's outcome depends on what
+// earlier queries of the same call claimed, so the device forms every candidate list of the call
+// (Frame::GetFeaturesInArea) with the Hamming distance of every candidate, and the host walks the lists in query
+// order exactly as the reference's loops do -- the walk reads distances, it computes none.
+// ---------------------------------------------------------------------------
+// after grid_upload(): CSR lists (off[Q+1], idx[]) in the reference's visiting order + dist[] per candidate
+static int grid_candidates(orbx_ctx* c, int N, int Q, float min_x, float min_y, float inv_w, float inv_h,
+                           std::vector<int32_t>& off, std::vector<int32_t>& idx, std::vector<uint16_t>& dist)
+{
+    const int stride = N > 0 ? N : 1;
+    int rc = grid_prepare(c, c->gq[0].as<orbx_keypoint>(), nullptr, N, stride, 1, min_x, min_y, inv_w, inv_h);
+    if (rc != ORBX_OK) return rc;
+    int32_t* d_cnt = c->gq[8].as<int32_t>();
+    int32_t* d_off = c->gq[9].as<int32_t>();
+    launch_grid_search(c->gq[0].as<orbx_keypoint>(), nullptr, c->grid_start.as<int>(), c->grid_list.as<int>(), stride, 1,
+                       c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(), c->gq[5].as<int32_t>(),
+                       c->gq[6].as<int32_t>(), nullptr, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, d_cnt, nullptr, nullptr, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    std::vector<int32_t> cnt(Q);
+    HIPCHECK(c, d2h(c, cnt.data(), d_cnt, (size_t)Q * 4));
+    HIPCHECK(c, finish(c));
+    off.assign((size_t)Q + 1, 0);
+    long long sum = 0;
+    for (int q = 0; q < Q; q++) { off[q] = (int32_t)sum; sum += cnt[q]; }
+    if (sum > 0x7fffffffLL) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates");
+    off[Q] = (int32_t)sum;
+    idx.assign((size_t)sum, 0);
+    dist.assign((size_t)sum, 0);
+    if (sum == 0) return ORBX_OK;
+    HIPCHECK(c, c->gq[11].ensure((size_t)sum * 4));
+    HIPCHECK(c, c->m2.ensure((size_t)sum * 2));
+    HIPCHECK(c, h2d(c, d_off, off.data(), (size_t)(Q + 1) * 4));
+    launch_grid_search(c->gq[0].as<orbx_keypoint>(), c->gq[1].as<uint32_t>(), c->grid_start.as<int>(), c->grid_list.as<int>(),
+                       stride, 1, c->gq[2].as<float>(), c->gq[3].as<float>(), c->gq[4].as<float>(), c->gq[5].as<int32_t>(),
+                       c->gq[6].as<int32_t>(), c->gq[7].as<uint32_t>(), nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, d_off, c->gq[11].as<int32_t>(), c->stream,
+                       c->m2.as<uint16_t>());
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, d2h(c, idx.data(), c->gq[11].p, (size_t)sum * 4));
+    HIPCHECK(c, d2h(c, dist.data(), c->m2.p, (size_t)sum * 2));
+    HIPCHECK(c, finish(c));
+    return ORBX_OK;
+}
+
+// ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1723-1764
+static void three_maxima(const std::vector<int32_t>* histo, int L, int& ind1, int& ind2, int& ind3)
+{
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = (int)histo[i].size();
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+
+int orbx_search_for_initialization(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d1, int n1,
+                                   const orbx_keypoint* k2, const uint32_t* d2, int n2, float min_x, float min_y,
+                                   float inv_w, float inv_h, float* prev_matched_xy, int window_size, float nnratio,
+                                   int check_orientation, int32_t* matches12, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (n1 < 0 || n2 < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (n1 == 0) return ORBX_OK;
+    if (!k1 || !d1 || !prev_matched_xy || !matches12 || (n2 > 0 && (!k2 || !d2))) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    constexpr int kHisto = 30, kThLow = 50;   // HISTO_LENGTH, TH_LOW (src/ORBmatcher.cc:37-39)
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    // the queries: keypoints of F1 on level 0 (:536-538), window around vbPrevMatched[i1] on level 0 of F2 (:540)
+    std::vector<int32_t> qi;
+    qi.reserve(n1);
+    for (int i = 0; i < n1; i++)
+        if (k1[i].octave <= 0) qi.push_back(i);
+    const int Q = (int)qi.size();
+    if (Q == 0 || n2 == 0) return ORBX_OK;
+    std::vector<float> qx(Q), qy(Q), qr(Q, (float)window_size);
+    std::vector<int32_t> ql(Q);
+    std::vector<uint32_t> qd((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) {
+        const int i = qi[q];
+        qx[q] = prev_matched_xy[2 * i];
+        qy[q] = prev_matched_xy[2 * i + 1];
+        ql[q] = k1[i].octave;
+        std::memcpy(&qd[(size_t)q * 8], d1 + (size_t)i * 8, 32);
+    }
+    int rc = grid_upload(c, k2, d2, n2, qx.data(), qy.data(), qr.data(), ql.data(), ql.data(), qd.data(), Q);
+    if (rc != ORBX_OK) return rc;
+    std::vector<int32_t> off, idx;
+    std::vector<uint16_t> dist;
+    rc = grid_candidates(c, n2, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    if (rc != ORBX_OK) return rc;
+
+    int nm = 0;
+    std::vector<int32_t> rotHist[kHisto];
+    const float factor = 1.0f / kHisto;
+    std::vector<int> vMatchedDistance(n2, 0x7fffffff), vnMatches21(n2, -1);
+    for (int q = 0; q < Q; q++) {
+        const int i1 = qi[q];
+        if (off[q + 1] == off[q]) continue;                                   // :542-543
+        int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx2 = -1;
+        for (int k = off[q]; k < off[q + 1]; k++) {
+            const int i2 = idx[k], d = dist[k];
+            if (vMatchedDistance[i2] <= d) continue;                          // :559-560
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        if (bestDist <= kThLow && bestDist < (float)bestDist2 * nnratio) {    // :574-576
+            if (vnMatches21[bestIdx2] >= 0) { matches12[vnMatches21[bestIdx2]] = -1; nm--; }   // :578-582
+            matches12[i1] = bestIdx2;
+            vnMatches21[bestIdx2] = i1;
+            vMatchedDistance[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) {                                          // :588-598
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == kHisto) bin = 0;
+                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");   // the reference asserts
+                rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_orientation) {                                                  // :603-625
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+        for (int i = 0; i < kHisto; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int i1 : rotHist[i])
+                if (matches12[i1] >= 0) { matches12[i1] = -1; nm--; }
+        }
+    }
+    for (int i1 = 0; i1 < n1; i1++)                                           // :628-630
+        if (matches12[i1] >= 0) {
+            prev_matched_xy[2 * i1] = k2[matches12[i1]].x;
+            prev_matched_xy[2 * i1 + 1] = k2[matches12[i1]].y;
+        }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                              float min_x, float min_y, float inv_w, float inv_h, const uint8_t* mp_track_in_view,
+                              const uint8_t* mp_is_bad, const float* mp_proj_x, const float* mp_proj_y,
+                              const float* mp_proj_xr, const int32_t* mp_level, const float* mp_view_cos,
+                              const uint32_t* mp_desc, const int32_t* mp_observations, int M, float th, float nnratio,
+                              int32_t* frame_obs, int32_t* frame_match, int32_t* match_score, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (M == 0 || N == 0) return ORBX_OK;
+    if (!kps || !desc || !mp_track_in_view || !mp_proj_x || !mp_proj_y || !mp_level || !mp_view_cos || !mp_desc ||
+        !mp_observations || !frame_obs || !frame_match || !match_score || (u_right && !mp_proj_xr))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    constexpr int kThHigh = 100;                      // TH_HIGH, src/ORBmatcher.cc:38
+    const bool bFactor = th != 1.0;                   // :159
+    // the queries: map points in view that are not bad (:164-168), window r * mvScaleFactors[level] on levels
+    // [level - 1, level] (:173-179)
+    std::vector<int32_t> qi;
+    qi.reserve(M);
+    for (int i = 0; i < M; i++) {
+        if (!mp_track_in_view[i] || (mp_is_bad && mp_is_bad[i])) continue;
+        if (mp_level[i] < 0 || mp_level[i] >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "predicted level out of range");
+        qi.push_back(i);
+    }
+    const int Q = (int)qi.size();
+    if (Q == 0) return ORBX_OK;
+    std::vector<float> qx(Q), qy(Q), qr(Q), rr(Q);
+    std::vector<int32_t> qmin(Q), qmax(Q);
+    std::vector<uint32_t> qd((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) {
+        const int i = qi[q];
+        float r = mp_view_cos[i] > 0.998 ? 2.5f : 4.0f;       // RadiusByViewingCos, :243-249
+        if (bFactor) r *= th;
+        rr[q] = r;
+        qx[q] = mp_proj_x[i];
+        qy[q] = mp_proj_y[i];
+        qr[q] = r * c->p.scale[mp_level[i]];
+        qmin[q] = mp_level[i] - 1;
+        qmax[q] = mp_level[i];
+        std::memcpy(&qd[(size_t)q * 8], mp_desc + (size_t)i * 8, 32);
+    }
+    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
+    if (rc != ORBX_OK) return rc;
+    std::vector<int32_t> off, idx;
+    std::vector<uint16_t> dist;
+    rc = grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    if (rc != ORBX_OK) return rc;
+
+    int nm = 0;
+    for (int q = 0; q < Q; q++) {
+        const int iMP = qi[q];
+        if (off[q + 1] == off[q]) continue;                                   // :181-182
+        const float r = rr[q];
+        const int lvl = mp_level[iMP];
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = off[q]; k < off[q + 1]; k++) {
+            const int i = idx[k];
+            if (frame_obs[i] > 0) continue;                                   // :197-199
+            if (u_right && u_right[i] > 0) {                                  // :201-206
+                const float er = fabsf(mp_proj_xr[iMP] - u_right[i]);
+                if (er > r * c->p.scale[lvl]) continue;
+            }
+            const int d = dist[k];
+            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = kps[i].octave; bestIdx = i; }
+            else if (d < bestDist2) { bestLevel2 = kps[i].octave; bestDist2 = d; }
+        }
+        if (bestDist <= kThHigh) {                                            // :228
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;   // :230-231
+            frame_match[bestIdx] = iMP;                                       // :233
+            frame_obs[bestIdx] = mp_observations[iMP];
+            match_score[bestIdx] = bestDist;                                  // :235
+            nm++;
+        }
+    }
+    *nmatches = nm;
     return ORBX_OK;
 }
 

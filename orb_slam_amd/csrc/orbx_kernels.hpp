@@ -123,6 +123,6 @@ void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, cons
                         const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, const int32_t* d_nq, int Q,
                         int q_stride, float minX, float minY, float invW, float invH, int32_t* best_idx,
                         int32_t* best_dist, int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl, int32_t* ncand,
-                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s);
+                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s, uint16_t* cand_dist = nullptr);
 
 } // namespace orbx

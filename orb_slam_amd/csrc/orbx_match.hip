@@ -386,9 +386,12 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
                              int32_t* d_second_dist, hipStream_t s)
 {
     // the matrix-core sweep needs whole tiles to pay: tiny problems keep the scalar form.  ORBX_MATCH_FORM=scalar takes
-    // it for every size (read per call: tests compare the two forms).
-    const char* e_form = getenv("ORBX_MATCH_FORM");
-    const bool scalar = (e_form && e_form[0] == 's') || getenv("ORBX_MATCH_NO_MFMA") != nullptr;
+    // it for every size.  The environment is read once per process; only a process started with
+    // ORBX_SWITCHES_PER_CALL set (the tests, which compare the two forms) reads it again at every call.
+    auto want_scalar = [] { const char* e = getenv("ORBX_MATCH_FORM"); return e && e[0] == 's'; };
+    static const bool per_call = getenv("ORBX_SWITCHES_PER_CALL") != nullptr;
+    static const bool scalar_at_start = want_scalar();
+    const bool scalar = per_call ? want_scalar() : scalar_at_start;
     if (!scalar && T >= 64 && q_stride >= 32) {
         const int per_wg = kFp4Waves * 32 * kMfmaQT;
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
@@ -1050,7 +1053,8 @@ __global__ __launch_bounds__(256) void k_grid_search(const orbx_keypoint* __rest
                                                      int32_t* __restrict__ best_idx, int32_t* __restrict__ best_dist,
                                                      int32_t* __restrict__ second_dist, int32_t* __restrict__ best_lvl,
                                                      int32_t* __restrict__ second_lvl, int32_t* __restrict__ ncand,
-                                                     const int32_t* __restrict__ cand_off, int32_t* __restrict__ cand_idx)
+                                                     const int32_t* __restrict__ cand_off, int32_t* __restrict__ cand_idx,
+                                                     uint16_t* __restrict__ cand_dist)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * 256 + threadIdx.x;
@@ -1094,20 +1098,22 @@ __global__ __launch_bounds__(256) void k_grid_search(const orbx_keypoint* __rest
                     if (maxLevel >= 0 && kp.octave > maxLevel) continue;
                 }
                 if (fabsf(__fsub_rn(kp.x, x)) < r && fabsf(__fsub_rn(kp.y, y)) < r) {
-                    if (LIST) cand_idx[wr++] = idx;
+                    if (LIST) cand_idx[wr] = idx;
                     if (has_desc) {
                         const uint4* tp = reinterpret_cast<const uint4*>(desc + (size_t)idx * 8);
                         const int d = hamming256(qd, tp[0], tp[1]);
+                        if (LIST && cand_dist) cand_dist[wr] = (uint16_t)d;   // every candidate's distance, for searches that exclude
                         const uint32_t key = ((uint32_t)d << 22) | (uint32_t)min(count, 0x3FFFFF);
                         if (key < best) { second = best; si = bi; best = key; bi = idx; }
                         else if (key < second) { second = key; si = idx; }
                     }
+                    if (LIST) wr++;
                     count++;
                 }
             }
         }
     if (ncand) ncand[qo] = count;
-    if (has_desc) {
+    if (has_desc && best_idx) {
         const bool bok = (best >> 22) < 256u, sok = (second >> 22) < 256u;
         best_idx[qo] = bok ? bi : -1;
         best_dist[qo] = (int32_t)(best >> 22);
@@ -1203,7 +1209,7 @@ void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, cons
                         const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, const int32_t* d_nq, int Q,
                         int q_stride, float minX, float minY, float invW, float invH, int32_t* best_idx,
                         int32_t* best_dist, int32_t* second_dist, int32_t* best_lvl, int32_t* second_lvl, int32_t* ncand,
-                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s)
+                        const int32_t* cand_off, int32_t* cand_idx, hipStream_t s, uint16_t* cand_dist)
 {
     if (q_stride <= 0) return;
     GridQueryArgs a{qx, qy, qr, qmin, qmax, qdesc, d_nq, Q, q_stride};
@@ -1217,11 +1223,11 @@ void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, cons
     if (cand_idx)
         hipLaunchKernelGGL(k_grid_search<true>, grid, dim3(256), 0, s, d_kps, d_desc, d_cell_start, d_cell_list, stride, a,
                            minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl, second_lvl, ncand, cand_off,
-                           cand_idx);
+                           cand_idx, cand_dist);
     else
         hipLaunchKernelGGL(k_grid_search<false>, grid, dim3(256), 0, s, d_kps, d_desc, d_cell_start, d_cell_list, stride, a,
                            minX, minY, invW, invH, best_idx, best_dist, second_dist, best_lvl, second_lvl, ncand, cand_off,
-                           cand_idx);
+                           cand_idx, cand_dist);
 }
 
 } // namespace orbx

@@ -197,3 +197,49 @@ class ORBmatcher:
             self._ctx, ptr(d_kps), ptr(d_desc), ptr(d_n), N, stride, nbatch, min_x, min_y, inv_w, inv_h,
             ptr(d_qx), ptr(d_qy), ptr(d_qr), ptr(d_qmin), ptr(d_qmax), ptr(d_qdesc), ptr(d_nq), Q, q_stride,
             ptr(d_bi), ptr(d_bd), ptr(d_sd), ptr(d_bl), ptr(d_sl), ptr(d_nc)))
+
+    # ---- searches with sequential exclusion ------------------------------------------------
+    def SearchForInitialization(self, keys1, desc1, keys2, desc2, grid, vbPrevMatched, windowSize=10):
+        """ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize)
+        (src/ORBmatcher.cc:520-633).  keys / desc: mvKeysUn / mDescriptors of the two frames; grid =
+        (mnMinX, mnMinY, mfGridElementWidthInv, mfGridElementHeightInv) of F2; vbPrevMatched: float32
+        array n1 x 2, updated in place.  Returns (nmatches, vnMatches12)."""
+        k1 = np.ascontiguousarray(keys1, KP_DTYPE)
+        k2 = np.ascontiguousarray(keys2, KP_DTYPE)
+        d1, d2 = _desc(desc1), _desc(desc2)
+        if vbPrevMatched.dtype != np.float32 or not vbPrevMatched.flags.c_contiguous or vbPrevMatched.shape != (len(k1), 2):
+            raise ValueError("vbPrevMatched must be a contiguous float32 array of shape (n1, 2)")
+        m12 = np.full(max(len(k1), 1), -1, np.int32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_for_initialization(
+            self._ctx, k1.ctypes.data, d1.ctypes.data, len(k1), k2.ctypes.data if len(k2) else None,
+            d2.ctypes.data if len(k2) else None, len(k2), grid[0], grid[1], grid[2], grid[3],
+            vbPrevMatched.ctypes.data, int(windowSize), self.mfNNratio, int(bool(self.mbCheckOrientation)),
+            m12.ctypes.data, C.byref(nm)))
+        return nm.value, m12[:len(k1)]
+
+    def SearchByProjection(self, keys, desc, mvuRight, grid, mp, th, frame_obs, frame_match, match_score):
+        """ORBmatcher::SearchByProjection(Frame&, const vector<MapPoint*>&, th) (src/ORBmatcher.cc:155-241).
+        mp: dict of per-map-point arrays (mbTrackInView, isBad, mTrackProjX, mTrackProjY, mTrackProjXR,
+        mnTrackScaleLevel, mTrackViewCos, descriptor, Observations); frame_obs / frame_match /
+        match_score: int32 arrays over the frame's keypoints, updated in place.  Returns nmatches."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        d = _desc(desc)
+        ur = None if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        for a in (frame_obs, frame_match, match_score):
+            if a.dtype != np.int32 or not a.flags.c_contiguous or len(a) < len(kps):
+                raise ValueError("frame arrays must be contiguous int32 arrays of N entries")
+        inview = np.ascontiguousarray(mp["mbTrackInView"], np.uint8)
+        bad = np.ascontiguousarray(mp["isBad"], np.uint8)
+        px, py, pxr, vc = (np.ascontiguousarray(mp[k], np.float32) for k in
+                           ("mTrackProjX", "mTrackProjY", "mTrackProjXR", "mTrackViewCos"))
+        lvl = np.ascontiguousarray(mp["mnTrackScaleLevel"], np.int32)
+        obs = np.ascontiguousarray(mp["Observations"], np.int32)
+        md = _desc(mp["descriptor"])
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_projection(
+            self._ctx, kps.ctypes.data, d.ctypes.data, ptr(ur), len(kps), grid[0], grid[1], grid[2], grid[3],
+            inview.ctypes.data, bad.ctypes.data, px.ctypes.data, py.ctypes.data, pxr.ctypes.data, lvl.ctypes.data,
+            vc.ctypes.data, md.ctypes.data, obs.ctypes.data, len(inview), float(th), self.mfNNratio,
+            frame_obs.ctypes.data, frame_match.ctypes.data, match_score.ctypes.data, C.byref(nm)))
+        return nm.value

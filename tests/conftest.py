@@ -9,6 +9,10 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# the library reads ORBX_MATCH_FORM once per process unless this is set before its first call: tests switch the form
+os.environ.setdefault("ORBX_SWITCHES_PER_CALL", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 

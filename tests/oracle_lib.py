@@ -99,6 +99,13 @@ class Oracle:
         lib.oo_stereo_one_point.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int, _f32p, C.c_int,
                                             C.c_float, _u8p, C.c_int, C.c_int, C.c_float, C.c_float,
                                             C.POINTER(StereoState), _i32p, _i32p]
+        lib.oo_three_maxima.argtypes = [_i32p, C.c_int, _i32p, _i32p, _i32p]
+        lib.oo_search_for_initialization.argtypes = [C.c_void_p, _u32p, C.c_int, C.c_void_p, _u32p, C.c_int,
+                                                     C.c_float, C.c_float, C.c_float, C.c_float, _f32p, C.c_int,
+                                                     C.c_float, C.c_int, _i32p]
+        lib.oo_search_by_projection.argtypes = [C.c_void_p, _u32p, _f32p, C.c_int, _f32p, C.c_float, C.c_float,
+                                                C.c_float, C.c_float, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p,
+                                                _u32p, _i32p, C.c_int, C.c_float, C.c_float, _i32p, _i32p, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -334,6 +341,50 @@ class Oracle:
         idx = np.zeros(max(total, 1), np.int32)
         self.lib.oo_features_in_area(*args, _ptr(idx, _i32p), total)
         return off, idx[:total]
+
+    def three_maxima(self, sizes):
+        sizes = np.ascontiguousarray(sizes, np.int32)
+        i1, i2, i3 = C.c_int32(-1), C.c_int32(-1), C.c_int32(-1)
+        self.lib.oo_three_maxima(_ptr(sizes, _i32p), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+        return i1.value, i2.value, i3.value
+
+    def search_for_initialization(self, k1, d1, k2, d2, grid, prev_matched, window, nnratio=0.9, check_ori=True):
+        """ORBmatcher::SearchForInitialization; prev_matched (n1 x 2 float32) is updated in place.
+        Returns (nmatches, vnMatches12)."""
+        k1 = np.ascontiguousarray(k1, KP_DTYPE)
+        k2 = np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        assert prev_matched.dtype == np.float32 and prev_matched.flags.c_contiguous and prev_matched.shape == (len(k1), 2)
+        m12 = np.full(max(len(k1), 1), -1, np.int32)
+        nm = self.lib.oo_search_for_initialization(k1.ctypes.data, _ptr(d1.view(np.uint32), _u32p), len(k1),
+                                                   k2.ctypes.data, _ptr(d2.view(np.uint32), _u32p), len(k2),
+                                                   grid[0], grid[1], grid[2], grid[3], _ptr(prev_matched, _f32p),
+                                                   int(window), nnratio, int(bool(check_ori)), _ptr(m12, _i32p))
+        return nm, m12[:len(k1)]
+
+    def search_by_projection(self, kps, desc, u_right, grid, mp, th, nnratio, frame_obs, frame_match, match_score):
+        """ORBmatcher::SearchByProjection(Frame&, vector<MapPoint*>&, th); the three frame arrays are
+        updated in place.  Returns nmatches."""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sf = self.tables()["scale"]
+        inview = np.ascontiguousarray(mp["mbTrackInView"], np.uint8)
+        bad = np.ascontiguousarray(mp["isBad"], np.uint8)
+        px, py, pxr, vc = (np.ascontiguousarray(mp[k], np.float32) for k in
+                           ("mTrackProjX", "mTrackProjY", "mTrackProjXR", "mTrackViewCos"))
+        lvl = np.ascontiguousarray(mp["mnTrackScaleLevel"], np.int32)
+        obs = np.ascontiguousarray(mp["Observations"], np.int32)
+        md = np.ascontiguousarray(mp["descriptor"], np.uint8).reshape(-1, 32)
+        for a in (frame_obs, frame_match, match_score):
+            assert a.dtype == np.int32 and a.flags.c_contiguous and len(a) >= len(kps)
+        return self.lib.oo_search_by_projection(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), len(kps),
+            _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3], _ptr(inview, _u8p), _ptr(bad, _u8p), _ptr(px, _f32p),
+            _ptr(py, _f32p), _ptr(pxr, _f32p), _ptr(lvl, _i32p), _ptr(vc, _f32p), _ptr(md.view(np.uint32), _u32p),
+            _ptr(obs, _i32p), len(inview), th, nnratio, _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
+            _ptr(match_score, _i32p))
 
     def undistort_points(self, xy, K, dist=None, R=None, P=None, fisheye=False):
         xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)

@@ -511,6 +511,41 @@ def test_recorded_launch_sequence_follows_its_arguments(oracle, euroc_left, euro
     ex.close()
 
 
+def test_recorded_launch_sequence_survives_geometry_changes_from_other_entry_points(oracle, euroc_left):
+    """The recording holds the addresses of the geometry tables.  Device-resident batches of another frame size
+    free and rebuild those tables without passing through the small host-fed path, and a device batch of the first
+    size then restores the geometry: the next host call must not replay the recording made before."""
+    import torch
+    from orb_slam_amd import ORBextractor
+    from orb_slam_amd.synth import synthetic_batch
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    ko, do = oracle.extract(euroc_left, literal=False)
+    dev = torch.device("cuda:0")
+
+    def device_batch(imgs):
+        b, h, w = imgs.shape
+        cap = ex.max_keypoints(w, h)
+        d_imgs = torch.from_numpy(imgs).to(dev)
+        d_k = torch.zeros((b, cap, 7), dtype=torch.float32, device=dev)
+        d_d = torch.zeros((b, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros((b,), dtype=torch.int32, device=dev)
+        ex.extract_batch_device(d_imgs, b, w, h, w, w * h, d_k, d_d, cap, d_n)
+        torch.cuda.synchronize()
+        return d_n.cpu().numpy()
+
+    for _ in range(4):                                           # plain, recording, replays
+        kg, dg = ex(euroc_left)
+        assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    for wide in (synthetic_batch(2, 1024, 256, seed0=77), synthetic_batch(2, 2048, 1100, seed0=78)):
+        assert (device_batch(wide) > 0).all()                    # other geometries: larger tables, reallocated
+        n = device_batch(np.stack([euroc_left, euroc_left]))     # the first geometry again, through the device path
+        assert n.tolist() == [len(ko), len(ko)]
+        for _ in range(3):
+            kg, dg = ex(euroc_left)                              # same arguments as the recording
+            assert np.array_equal(kg, ko) and np.array_equal(dg, do)
+    ex.close()
+
+
 def test_small_feature_budget_and_tiny_levels():
     """nfeatures = 40 (Tracking::updateORBExtractor re-creates extractors with small budgets):
     N per level below 4*nIni, and a 200x150 image whose top levels are too small to search."""

@@ -1,5 +1,6 @@
-"""GPU path against the committed golden fixture (tests/golden/euroc_golden.npz, written by
-tools/gen_golden.py from the reference's EuRoC test pair): no oracle call in this file, only
+"""GPU path against the committed golden fixtures (tests/golden/{euroc,tum}_golden.npz, written by
+tools/gen_golden.py from the reference's two test pairs: EuRoC 752x480, and the 512x512 TUM pair
+test/test_Stereo.cpp loads, a square frame with a single quadtree root): no oracle call in this file, only
 liborbx through the C ABI and the stored vectors."""
 import hashlib
 import os
@@ -12,13 +13,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def golden():
-    return np.load(os.path.join(ROOT, "tests", "golden", "euroc_golden.npz"))
+@pytest.fixture(scope="module", params=["euroc", "tum"])
+def pair(request):
+    fix = {"euroc": "EuRoC", "tum": "TUM"}[request.param]
+    g = np.load(os.path.join(ROOT, "tests", "golden", request.param + "_golden.npz"))
+    left = np.load(os.path.join(ROOT, "tests", "fixtures", fix + "_l.npy"))
+    right = np.load(os.path.join(ROOT, "tests", "fixtures", fix + "_r.npy"))
+    return g, left, right
 
 
-def test_extraction_matches_golden(golden, euroc_left, euroc_right):
+def test_extraction_matches_golden(pair):
     from orb_slam_amd import ORBextractor
+    golden, euroc_left, euroc_right = pair
     ex = ORBextractor(1000, 1.2, 8, 20, 7)
     try:
         kl, dl = ex(euroc_left)
@@ -39,8 +45,9 @@ def test_extraction_matches_golden(golden, euroc_left, euroc_right):
         ex.close()
 
 
-def test_matching_matches_golden(golden):
+def test_matching_matches_golden(pair):
     from orb_slam_amd import ORBextractor, ORBmatcher
+    golden, left, _ = pair
     ex = ORBextractor(1000, 1.2, 8, 20, 7)
     try:
         m = ORBmatcher(ex)
@@ -49,7 +56,7 @@ def test_matching_matches_golden(golden):
         assert np.array_equal(bi, golden["bf_best_idx"]) and np.array_equal(bd, golden["bf_best_dist"])
         assert np.array_equal(sd, golden["bf_second_dist"])
         mbf, mb = (float(v) for v in golden["stereo_params"])
-        si, sdist, ur, dp, nm = m.stereo_match(kl, dl, kr, dr, 480, mbf, mb)
+        si, sdist, ur, dp, nm = m.stereo_match(kl, dl, kr, dr, left.shape[0], mbf, mb)
         assert np.array_equal(si, golden["stereo_best_idx"]) and np.array_equal(sdist, golden["stereo_best_dist"])
         assert nm == int(golden["stereo_nmatched"])
         assert np.array_equal(ur, golden["stereo_u_right"]) and np.array_equal(dp, golden["stereo_depth"])

@@ -1,0 +1,186 @@
+"""GPU parity of the two search routines whose queries exclude what earlier queries claimed
+(ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:520-633; ORBmatcher::SearchByProjection(Frame&,
+vector<MapPoint*>&, th), :155-241) against the CPU oracle: the device forms the candidate lists and every
+candidate distance, the library walks them in query order.  Every output array must be bit-identical."""
+import numpy as np
+import pytest
+
+from orb_slam_amd import KP_DTYPE
+from test_oracle_search import GRID, _map_points, _random_frames
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ini():
+    """the monocular initialisation extractor of the reference: 2000 features (src/Tracking.cc:279)"""
+    from orb_slam_amd import ORBextractor
+    ex = ORBextractor(2000, 1.2, 8, 20, 7)
+    yield ex
+    ex.close()
+
+
+def _both_init(matcher, oracle, k1, d1, k2, d2, prev, window, ratio, ori):
+    from orb_slam_amd import ORBmatcher
+    m = ORBmatcher(matcher._ex, nnratio=ratio, checkOri=ori)
+    pg, po = prev.copy(), prev.copy()
+    nm_g, m_g = m.SearchForInitialization(k1, d1, k2, d2, GRID, pg, window)
+    nm_o, m_o = oracle.search_for_initialization(k1, d1, k2, d2, GRID, po, window, ratio, ori)
+    assert nm_g == nm_o
+    assert np.array_equal(m_g, m_o)
+    assert np.array_equal(pg, po)
+    return nm_g, m_g, pg
+
+
+@pytest.fixture(scope="module")
+def matcher(ini):
+    from orb_slam_amd import ORBmatcher
+    return ORBmatcher(ini, nnratio=0.9, checkOri=True)
+
+
+def test_initialization_search_on_the_euroc_pair(ini, matcher, oracle, euroc_left, euroc_right):
+    """Tracking::MonocularInitialization (src/Tracking.cc:1175-1180): matcher(0.9, true), window 100, vbPrevMatched =
+    the first frame's keypoint positions; then the next call with the vector the first one updated."""
+    k1, d1 = ini(euroc_left)
+    k2, d2 = ini(euroc_right)
+    assert len(k1) > 1800 and len(k2) > 1800
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    for ori in (True, False):
+        nm, m12, prev2 = _both_init(matcher, oracle, k1, d1, k2, d2, prev, 100, 0.9, ori)
+        assert nm > 50
+        # steals happened: some F2 keypoint was the best of several F1 keypoints, only one holds it
+        assert len(set(m12[m12 >= 0].tolist())) == (m12 >= 0).sum()
+    # frame after frame: the updated positions, a narrower window, the frames swapped
+    _both_init(matcher, oracle, k1, d1, k2, d2, prev2, 30, 0.9, True)
+    _both_init(matcher, oracle, k2, d2, k1, d1, np.stack([k2["x"], k2["y"]], 1).astype(np.float32), 100, 0.9, True)
+
+
+def test_initialization_search_on_a_synthetic_pair(ini, matcher, oracle):
+    from orb_slam_amd.synth import synthetic_frame
+    a = synthetic_frame(752, 480, seed=9100)
+    b = np.roll(a, (3, -7), axis=(0, 1))                 # the same scene moved by (-7, 3)
+    k1, d1 = ini(a)
+    k2, d2 = ini(b)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    nm, m12, _ = _both_init(matcher, oracle, k1, d1, k2, d2, prev, 100, 0.9, True)
+    assert nm > 150
+    sel = m12 >= 0
+    dx = k2["x"][m12[sel]] - k1["x"][sel]
+    assert np.median(dx) == -7.0
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_initialization_search_with_forced_steals_and_ties(matcher, oracle, seed):
+    """look-alike descriptors (a few prototypes), crowded windows: equal distances, claims that collide,
+    un-matching (:578-582) and the `<=` skip (:559-560) all occur"""
+    rng = np.random.default_rng(seed)
+    n1, n2 = 1500, 1700
+    k1, d1, k2, d2 = _random_frames(rng, n1, n2, clusters=12)
+    k2["x"][:n1] = k1["x"] + rng.integers(-6, 7, n1).astype(np.float32)
+    k2["y"][:n1] = k1["y"] + rng.integers(-6, 7, n1).astype(np.float32)
+    bits = np.unpackbits(d1, axis=1)
+    d2[:n1] = np.packbits(bits ^ (rng.random(bits.shape) < 0.02), axis=1)
+    # exact duplicates: several F1 keypoints with the same descriptor and position compete for one F2 keypoint
+    d1[1::7] = d1[0:-1:7][:len(d1[1::7])]
+    k1["x"][1::7], k1["y"][1::7] = k1["x"][0:-1:7][:len(k1["x"][1::7])], k1["y"][0:-1:7][:len(k1["x"][1::7])]
+    k1["octave"][1::7] = 0
+    k1["octave"][0::7] = 0
+    k2["angle"][:n1] = ((k1["angle"] + rng.choice([0.0, 0.0, 2.0, 90.0, 185.0], n1)) % 360).astype(np.float32)
+    k2["octave"][:n1] = np.where(rng.random(n1) < 0.8, 0, k2["octave"][:n1])
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    for ratio, ori, window in ((0.9, True, 25), (0.6, False, 60), (1.0, True, 10)):
+        nm, m12, _ = _both_init(matcher, oracle, k1, d1, k2, d2, prev, window, ratio, ori)
+        assert nm > 50
+
+
+def test_initialization_search_edge_cases(matcher, oracle):
+    rng = np.random.default_rng(3)
+    k1, d1, k2, d2 = _random_frames(rng, 40, 50, clusters=3)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    # an empty second frame, an empty first frame, no keypoint on level 0, windows outside the image
+    nm, m12 = matcher.SearchForInitialization(k1, d1, k2[:0], d2[:0], GRID, prev.copy(), 100)
+    assert nm == 0 and (m12 == -1).all()
+    nm, m12 = matcher.SearchForInitialization(k1[:0], d1[:0], k2, d2, GRID, np.zeros((0, 2), np.float32), 100)
+    assert nm == 0 and len(m12) == 0
+    k1b = k1.copy()
+    k1b["octave"] = 2
+    _both_init(matcher, oracle, k1b, d1, k2, d2, prev, 100, 0.9, True)
+    far = prev + np.float32(5000)
+    nm, _, _ = _both_init(matcher, oracle, k1, d1, k2, d2, far, 100, 0.9, True)
+    assert nm == 0
+    # negative coordinates and keypoints outside the grid (undistortion can push them out)
+    k2b = k2.copy()
+    k2b["x"][::5] -= 800
+    _both_init(matcher, oracle, k1, d1, k2b, d2, prev - np.float32(20), 300, 0.9, False)
+
+
+def _both_projection(matcher, oracle, kps, desc, u_right, mp, th, ratio, obs0):
+    from orb_slam_amd import ORBmatcher
+    m = ORBmatcher(matcher._ex, nnratio=ratio)
+    res = []
+    for side in (m, oracle):
+        fo, fm, ms = obs0.copy(), np.full(len(kps), -1, np.int32), np.full(len(kps), -1, np.int32)
+        if side is oracle:
+            nm = oracle.search_by_projection(kps, desc, u_right, GRID, mp, th, ratio, fo, fm, ms)
+        else:
+            nm = m.SearchByProjection(kps, desc, u_right, GRID, mp, th, fo, fm, ms)
+        res.append((nm, fo, fm, ms))
+    assert res[0][0] == res[1][0]
+    for a, b in zip(res[0][1:], res[1][1:]):
+        assert np.array_equal(a, b)
+    return res[0]
+
+
+def test_projection_search_on_the_euroc_pair(oracle, euroc_left, euroc_right):
+    """Tracking::SearchLocalPoints (src/Tracking.cc:2437-2441): local map points projected into the current frame.
+    Map points = the right image's keypoints seen from the left frame (projection = the keypoint the row-band
+    stereo search paired it with, jittered), descriptors from the right image, th = 1 and 3 (:2431-2436)."""
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex, nnratio=0.8)
+    kl, dl = ex(euroc_left)
+    kr, dr = ex(euroc_right)
+    bi, bd, ur, dp, _ = m.stereo_match(kl, dl, kr, dr, 480, 47.9, 0.11, 0.0)
+    rng = np.random.default_rng(77)
+    has = np.nonzero(bi >= 0)[0]
+    M = len(has)
+    assert M > 300
+    mp = {
+        "mbTrackInView": (rng.random(M) < 0.95).astype(np.uint8),
+        "isBad": (rng.random(M) < 0.03).astype(np.uint8),
+        "mTrackProjX": (kl["x"][has] + rng.normal(0, 1.0, M)).astype(np.float32),
+        "mTrackProjY": (kl["y"][has] + rng.normal(0, 1.0, M)).astype(np.float32),
+        "mTrackProjXR": (kr["x"][bi[has]] + rng.normal(0, 1.0, M)).astype(np.float32),
+        "mnTrackScaleLevel": kl["octave"][has].astype(np.int32),
+        "mTrackViewCos": rng.choice([0.95, 0.9995], M).astype(np.float32),
+        "Observations": rng.choice([0, 2, 5], M).astype(np.int32),
+        "descriptor": dr[bi[has]],
+    }
+    obs0 = np.where(rng.random(len(kl)) < 0.1, 3, -1).astype(np.int32)
+    for th in (1.0, 3.0):
+        for u_right in (ur, None):
+            nm, fo, fm, ms = _both_projection(m, oracle, kl, dl, u_right, mp, th, 0.8, obs0)
+            assert nm > 200
+    ex.close()
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(21, False, 1.0), (22, True, 1.0), (23, True, 5.0), (24, False, 3.0)])
+def test_projection_search_with_collisions(matcher, oracle, seed, stereo, th):
+    """many map points per keypoint neighbourhood: claims by points with and without observations, overwrites,
+    the same-level ratio test, the right-image gate"""
+    rng = np.random.default_rng(seed)
+    kps, desc, _, _ = _random_frames(rng, 3000, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    sf = oracle.tables()["scale"]
+    mp = _map_points(rng, kps, desc, 4000, sf)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.random(len(kps)).astype(np.float32) * 30, -1).astype(np.float32)
+    obs0 = rng.choice([-1, -1, -1, 0, 2], len(kps)).astype(np.int32)
+    nm, fo, fm, ms = _both_projection(matcher, oracle, kps, desc, u_right, mp, th, 0.8, obs0)
+    assert nm > 500
+    # empty inputs
+    e = {k: v[:0] for k, v in mp.items()}
+    assert _both_projection(matcher, oracle, kps, desc, u_right, e, th, 0.8, obs0)[0] == 0
+    none_in_view = dict(mp, mbTrackInView=np.zeros(len(mp["isBad"]), np.uint8))
+    assert _both_projection(matcher, oracle, kps, desc, u_right, none_in_view, th, 0.8, obs0)[0] == 0

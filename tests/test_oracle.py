@@ -374,6 +374,32 @@ def test_golden_fixture(euroc_left, euroc_right):
     assert hashlib.sha256(euroc_right.tobytes()).hexdigest()[:16] == "51ea6e72e9473f40"
 
 
+def test_golden_fixture_tum():
+    """the pair the reference's own stereo test loads (test/test_Stereo.cpp:94-95): 512 x 512, one quadtree root,
+    dark images whose last levels have fewer candidates than features asked for"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tum_golden.npz"))
+    left = np.load(os.path.join(ROOT, "tests", "fixtures", "TUM_l.npy"))
+    right = np.load(os.path.join(ROOT, "tests", "fixtures", "TUM_r.npy"))
+    assert left.shape == (512, 512) and left.dtype == np.uint8
+    assert hashlib.sha256(left.tobytes()).hexdigest()[:16] == "238f451bb2b921cf"
+    assert hashlib.sha256(right.tobytes()).hexdigest()[:16] == "c3715204d6334d5a"
+    o = Oracle(1000, 1.2, 8, 20, 7)
+    for lit in (True, False):
+        kl, dl = o.extract(left, literal=lit)
+        assert np.array_equal(kl, g["kps_l"]) and np.array_equal(dl, g["desc_l"])
+        assert np.array_equal(o.last_level_counts(), g["counts_l"])
+    assert (g["counts_l"][6:] < [73, 60]).any()          # a level that runs short of candidates
+    assert [len(o.detect_level(l, True)) for l in range(8)] == g["ncand_l"].tolist()
+    kr, dr = o.extract(right, literal=True)
+    assert np.array_equal(kr, g["kps_r"]) and np.array_equal(dr, g["desc_r"])
+    mbf, mb = (float(v) for v in g["stereo_params"])
+    maxD = float(np.float32(mbf) / np.float32(mb))
+    bi, bd = o.stereo_search(kl, dl, kr, dr, o.tables()["scale"], 512, 0.0, maxD, 0.0)
+    assert np.array_equal(bi, g["stereo_best_idx"]) and np.array_equal(bd, g["stereo_best_dist"])
+    nm, ur, dp = o.stereo_finish(kl, kr, bi, bd, mbf, 0.0, maxD)
+    assert nm == int(g["stereo_nmatched"]) and np.array_equal(ur, g["stereo_u_right"]) and np.array_equal(dp, g["stereo_depth"])
+
+
 def test_stereo_row_band_semantics(oracle):
     sf = oracle.tables()["scale"]
     kl = np.zeros(2, KP_DTYPE)

@@ -1,0 +1,385 @@
+"""The oracle's restatement of the two search routines with sequential exclusion
+(ORBmatcher::SearchForInitialization, src/ORBmatcher.cc:520-633; ORBmatcher::SearchByProjection(Frame&,
+vector<MapPoint*>&, th), :155-241): hand-computed known answers for every rule of the loops, and a second,
+independent statement of each loop in plain Python (per-query GetFeaturesInArea by brute force over all
+keypoints, no CSR lists) that must give the same arrays on random frames.  No GPU."""
+import numpy as np
+import pytest
+
+from oracle_lib import KP_DTYPE
+
+GRID = (0.0, 0.0, float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480)))
+
+
+def _kps(xy, octave=0, angle=0.0):
+    k = np.zeros(len(xy), KP_DTYPE)
+    k["x"] = [p[0] for p in xy]
+    k["y"] = [p[1] for p in xy]
+    k["size"] = 31
+    k["angle"] = angle
+    k["octave"] = octave
+    k["class_id"] = -1
+    return k
+
+
+def _desc_with_bits(nbits_list):
+    """descriptors with the given number of leading one-bits: distance between two of them = |a - b|"""
+    d = np.zeros((len(nbits_list), 32), np.uint8)
+    for i, n in enumerate(nbits_list):
+        bits = np.zeros(256, np.uint8)
+        bits[:n] = 1
+        d[i] = np.packbits(bits, bitorder="little")
+    return d
+
+
+def test_three_maxima(oracle):
+    # src/ORBmatcher.cc:1723-1764: the three largest bins, the 2nd / 3rd dropped below 10 % of the largest
+    assert oracle.three_maxima([0] * 30) == (-1, -1, -1)
+    s = [0] * 30
+    s[4], s[9], s[20] = 50, 30, 10
+    assert oracle.three_maxima(s) == (4, 9, 20)
+    s[20] = 4                         # 4 < 0.1 * 50
+    assert oracle.three_maxima(s) == (4, 9, -1)
+    s[9] = 4
+    assert oracle.three_maxima(s) == (4, -1, -1)
+    # ties: strict '>' keeps the first bin of equal size in front
+    s = [0] * 30
+    s[3] = s[7] = s[8] = s[9] = 5
+    assert oracle.three_maxima(s) == (3, 7, 8)
+    # a later larger bin shifts the earlier ones down
+    s = [1, 2, 3, 4] + [0] * 26
+    assert oracle.three_maxima(s) == (3, 2, 1)
+
+
+def test_init_search_rules(oracle):
+    # F2: three keypoints close together; F1: queries all looking at the same window
+    k2 = _kps([(100, 100), (104, 100), (300, 300)])
+    d2 = _desc_with_bits([0, 40, 0])
+    # query 0: distances 10 / 30 to the first two -> best 10 (idx 0), second 30; 10 < 0.9 * 30 -> match
+    # query 1: distances 5 / 35: candidate 0 is held at 10 > 5 -> steals it, query 0 is un-matched
+    # query 2: distance 5 to candidate 0 as well: vMatchedDistance[0] = 5 <= 5 -> candidate skipped; best = 35 (idx 1)
+    #          second = INT_MAX -> 35 <= 50 and 35 < 0.9 * INT_MAX -> matches idx 1
+    # query 3: on level 1 -> skipped; query 4: window holds no keypoint
+    k1 = _kps([(100, 100)] * 5, octave=[0, 0, 0, 1, 0])
+    d1 = _desc_with_bits([10, 5, 5, 0, 0])
+    prev = np.array([[101, 101]] * 4 + [[600, 50]], np.float32)
+    nm, m12 = oracle.search_for_initialization(k1, d1, k2, d2, GRID, prev, 10, nnratio=0.9, check_ori=False)
+    assert m12.tolist() == [-1, 0, 1, -1, -1] and nm == 2
+    # vbPrevMatched follows the matches (:628-630), the rest keeps its value
+    assert prev.tolist() == [[101, 101], [100, 100], [104, 100], [101, 101], [600, 50]]
+    # TH_LOW: a best distance of 51 is refused, 50 accepted (:574)
+    for bits, want in ((51, -1), (50, 0)):
+        prev = np.array([[100, 100]], np.float32)
+        nm, m12 = oracle.search_for_initialization(_kps([(100, 100)]), _desc_with_bits([bits]), k2[:1], d2[:1], GRID, prev,
+                                                   10, 0.9, False)
+        assert m12.tolist() == [want] and nm == (want >= 0)
+    # ratio test is strict and in float: best 27, second 30, ratio 0.9 -> 27 < 27.0 fails
+    k2b = _kps([(100, 100), (104, 100)])
+    prev = np.array([[100, 100]], np.float32)
+    nm, m12 = oracle.search_for_initialization(_kps([(100, 100)]), _desc_with_bits([27]), k2b, _desc_with_bits([0, 57]), GRID,
+                                               prev, 10, 0.9, False)
+    assert m12.tolist() == [-1] and nm == 0
+    # equal distances: the first candidate in list order is kept as best, the other becomes the second (:562-571)
+    prev = np.array([[100, 100]], np.float32)
+    nm, m12 = oracle.search_for_initialization(_kps([(100, 100)]), _desc_with_bits([10]), k2b, _desc_with_bits([0, 20]), GRID,
+                                               prev, 10, 0.9, False)
+    assert m12.tolist() == [-1]       # 10 < 0.9 * 10 fails
+    # window: |dx| < r strictly (src/Frame.cc:715)
+    prev = np.array([[110, 100]], np.float32)
+    nm, m12 = oracle.search_for_initialization(_kps([(0, 0)]), _desc_with_bits([0]), k2[:1], d2[:1], GRID, prev, 10, 0.9, False)
+    assert nm == 0
+    prev = np.array([[109.5, 100]], np.float32)
+    nm, m12 = oracle.search_for_initialization(_kps([(0, 0)]), _desc_with_bits([0]), k2[:1], d2[:1], GRID, prev, 10, 0.9, False)
+    assert nm == 1
+    # level filter of GetFeaturesInArea(…, 0, 0): a candidate on level 1 is not seen
+    k2c = _kps([(100, 100)], octave=1)
+    prev = np.array([[100, 100]], np.float32)
+    nm, m12 = oracle.search_for_initialization(_kps([(0, 0)]), _desc_with_bits([0]), k2c, d2[:1], GRID, prev, 10, 0.9, False)
+    assert nm == 0
+
+
+def test_init_search_rotation_histogram(oracle):
+    # 10 matches with rotation 0 deg, 2 with 95 deg, 1 with 200 deg, 1 with 300 deg.  bin = round(rot / 30):
+    # bins 0 (10), 3 (2), 7 (1), 10 (1).  Three maxima: 0, 3, 7 (first of the equal ones); 1 < 0.1 * 10 is false,
+    # so the third stays.  The match in bin 10 is removed.
+    n = 14
+    xy = [(40 + 40 * i, 60 + 20 * (i % 3)) for i in range(n)]
+    rot = [0.0] * 10 + [95.0, 95.0, 200.0, 300.0]
+    k2 = _kps(xy, angle=0.0)
+    k1 = _kps(xy, angle=rot)
+    rng = np.random.default_rng(5)
+    d = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    prev = np.array(xy, np.float32)
+    nm, m12 = oracle.search_for_initialization(k1, d, k2, d, GRID, prev.copy(), 5, 0.9, True)
+    assert m12.tolist() == list(range(13)) + [-1] and nm == 13
+    nm, m12 = oracle.search_for_initialization(k1, d, k2, d, GRID, prev.copy(), 5, 0.9, False)
+    assert m12.tolist() == list(range(14)) and nm == 14
+    # with 12 matches in the first bin the third maximum (1 < 0.1 * 12) is dropped as well (:1760-1763)
+    xy2 = xy + [(60 + 40 * i, 200) for i in range(2)]
+    k2c, k1c = _kps(xy2, angle=0.0), _kps(xy2, angle=rot + [0.0, 0.0])
+    d2c = rng.integers(0, 256, (16, 32), dtype=np.uint8)
+    nm, m12 = oracle.search_for_initialization(k1c, d2c, k2c, d2c, GRID, np.array(xy2, np.float32), 5, 0.9, True)
+    assert m12.tolist() == list(range(12)) + [-1, -1, 14, 15] and nm == 14
+    # negative difference wraps by 360 (:591-592): angle1 = 10, angle2 = 350 -> rot = 20 -> bin round(0.667) = 1
+    k1b, k2b = _kps(xy, angle=10.0), _kps(xy, angle=350.0)
+    k1b["angle"][0] = 350.0      # rot 0 -> bin 0, alone: second maximum, but 1 < 0.1 * 13 drops it
+    nm, m12 = oracle.search_for_initialization(k1b, d, k2b, d, GRID, prev.copy(), 5, 0.9, True)
+    assert nm == 13 and m12[0] == -1
+
+
+def _py_features_in_area(kps, grid, x, y, r, min_level, max_level):
+    """Frame::GetFeaturesInArea (src/Frame.cc:669-722) by its definition: cells in column-major window
+    order, keypoints of a cell in index order (PosInGrid :724-734)"""
+    min_x, min_y, inv_w, inv_h = (np.float32(v) for v in grid)
+    x, y, r = np.float32(x), np.float32(y), np.float32(r)
+    cx0 = max(0, int(np.floor((x - min_x - r) * inv_w)))
+    cx1 = min(63, int(np.ceil((x - min_x + r) * inv_w)))
+    cy0 = max(0, int(np.floor((y - min_y - r) * inv_h)))
+    cy1 = min(47, int(np.ceil((y - min_y + r) * inv_h)))
+    if cx0 >= 64 or cx1 < 0 or cy0 >= 48 or cy1 < 0:
+        return []
+    px = np.round((kps["x"] - min_x) * inv_w).astype(int)      # all test coordinates are away from .5 cell positions
+    py = np.round((kps["y"] - min_y) * inv_h).astype(int)
+    out = []
+    check = min_level > 0 or max_level >= 0
+    for ix in range(cx0, cx1 + 1):
+        for iy in range(cy0, cy1 + 1):
+            for i in np.nonzero((px == ix) & (py == iy))[0]:
+                if check and (kps["octave"][i] < min_level or (max_level >= 0 and kps["octave"][i] > max_level)):
+                    continue
+                if abs(kps["x"][i] - x) < r and abs(kps["y"][i] - y) < r:
+                    out.append(int(i))
+    return out
+
+
+def _ham(a, b):
+    return int(np.unpackbits(a ^ b).sum())
+
+
+def _py_search_for_initialization(k1, d1, k2, d2, grid, prev, window, nnratio, check_ori):
+    n1, n2 = len(k1), len(k2)
+    m12 = [-1] * n1
+    m21 = [-1] * n2
+    md = [2 ** 31 - 1] * n2
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for i1 in range(n1):
+        if k1["octave"][i1] > 0:
+            continue
+        cands = _py_features_in_area(k2, grid, prev[i1, 0], prev[i1, 1], window, 0, 0)
+        best, best2, bi = 2 ** 31 - 1, 2 ** 31 - 1, -1
+        for i2 in cands:
+            dist = _ham(d1[i1], d2[i2])
+            if md[i2] <= dist:
+                continue
+            if dist < best:
+                best2, best, bi = best, dist, i2
+            elif dist < best2:
+                best2 = dist
+        if best <= 50 and np.float32(best) < np.float32(best2) * np.float32(nnratio):
+            if m21[bi] >= 0:
+                m12[m21[bi]] = -1
+                nm -= 1
+            m12[i1], m21[bi], md[bi] = bi, i1, best
+            nm += 1
+            if check_ori:
+                rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360))
+                v = float(np.float32(rot * np.float32(1.0 / 30)))
+                b = int(np.floor(v + 0.5))          # C round(): half away from zero, v >= 0 here
+                if b == 30:
+                    b = 0
+                hist[b].append(i1)
+    if check_ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: (-sizes[i], i))[:3]
+        keep = [order[0]] if sizes[order[0]] > 0 else []
+        for o in order[1:]:
+            if sizes[o] > 0 and not (np.float32(sizes[o]) < np.float32(0.1) * np.float32(sizes[order[0]])):
+                keep.append(o)
+            else:
+                break
+        for i in range(30):
+            if i in keep:
+                continue
+            for i1 in hist[i]:
+                if m12[i1] >= 0:
+                    m12[i1] = -1
+                    nm -= 1
+    for i1 in range(n1):
+        if m12[i1] >= 0:
+            prev[i1] = (k2["x"][m12[i1]], k2["y"][m12[i1]])
+    return nm, m12
+
+
+def _random_frames(rng, n1, n2, clusters):
+    """two keypoint sets that share structure: F2 = F1 moved a little, descriptors = a few prototypes with
+    bit flips, so that windows hold several candidates at close (and equal) distances and claims collide"""
+    protos = rng.integers(0, 256, (clusters, 32), dtype=np.uint8)
+
+    def descs(n):
+        d = protos[rng.integers(0, clusters, n)].copy()
+        bits = np.unpackbits(d, axis=1)
+        flip = rng.random(bits.shape) < 0.03
+        return np.packbits(bits ^ flip, axis=1)
+
+    def keys(n):
+        k = np.zeros(n, KP_DTYPE)
+        k["x"] = (rng.integers(0, 7500, n) / 10 + 0.03).astype(np.float32)
+        k["y"] = (rng.integers(0, 4780, n) / 10 + 0.03).astype(np.float32)
+        k["angle"] = (rng.random(n) * 360).astype(np.float32)
+        k["octave"] = rng.choice([0, 0, 0, 1, 2], n)
+        k["size"] = 31
+        k["class_id"] = -1
+        return k
+
+    return keys(n1), descs(n1), keys(n2), descs(n2)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_init_search_against_python_statement(oracle, seed):
+    rng = np.random.default_rng(seed)
+    k1, d1, k2, d2 = _random_frames(rng, 300, 350, clusters=25)
+    # crowd F2 around F1's points so that the windows are busy
+    k2["x"][:300] = k1["x"] + rng.integers(-8, 9, 300).astype(np.float32)
+    k2["y"][:300] = k1["y"] + rng.integers(-8, 9, 300).astype(np.float32)
+    # true correspondences (a few bits flipped, most of them rotated alike) among look-alikes of the same cluster
+    bits = np.unpackbits(d1, axis=1)
+    d2[:300] = np.packbits(bits ^ (rng.random(bits.shape) < 0.02), axis=1)
+    k2["angle"][:300] = ((k1["angle"] + rng.choice([0.0, 0.0, 0.0, 3.0, 100.0, 170.0], 300)) % 360).astype(np.float32)
+    k2["octave"][:300] = np.where(rng.random(300) < 0.85, 0, k2["octave"][:300])
+    for check_ori in (False, True):
+        prev_o = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+        prev_p = prev_o.copy()
+        nm_o, m_o = oracle.search_for_initialization(k1, d1, k2, d2, GRID, prev_o, 40, 0.9, check_ori)
+        nm_p, m_p = _py_search_for_initialization(k1, d1, k2, d2, GRID, prev_p, 40, 0.9, check_ori)
+        assert nm_o == nm_p and m_o.tolist() == m_p
+        assert np.array_equal(prev_o, prev_p)
+        assert nm_o > 40                         # the case is not vacuous
+    # steals did happen: some F1 keypoint with candidates ends unmatched although it was best for someone
+
+
+def _map_points(rng, kps, desc, M, sf):
+    """map points projected near keypoints of the frame, descriptors = those keypoints' with bit flips"""
+    pick = rng.integers(0, len(kps), M)
+    lvl = np.clip(kps["octave"][pick] + rng.integers(0, 2, M), 0, 7).astype(np.int32)
+    mp = {
+        "mbTrackInView": (rng.random(M) < 0.9).astype(np.uint8),
+        "isBad": (rng.random(M) < 0.05).astype(np.uint8),
+        "mTrackProjX": (kps["x"][pick] + rng.normal(0, 1.5, M)).astype(np.float32),
+        "mTrackProjY": (kps["y"][pick] + rng.normal(0, 1.5, M)).astype(np.float32),
+        "mnTrackScaleLevel": lvl,
+        "mTrackViewCos": rng.choice([0.9, 0.9985, 0.999, 0.5], M).astype(np.float32),
+        "Observations": rng.choice([0, 1, 3, 7], M).astype(np.int32),
+    }
+    mp["mTrackProjXR"] = (mp["mTrackProjX"] - rng.random(M).astype(np.float32) * 30).astype(np.float32)
+    bits = np.unpackbits(desc[pick], axis=1)
+    flip = rng.random(bits.shape) < 0.06
+    mp["descriptor"] = np.packbits(bits ^ flip, axis=1)
+    return mp
+
+
+def _py_search_by_projection(kps, desc, u_right, grid, mp, th, nnratio, sf, frame_obs, frame_match, match_score):
+    nm = 0
+    for i in range(len(mp["mbTrackInView"])):
+        if not mp["mbTrackInView"][i] or mp["isBad"][i]:
+            continue
+        lvl = int(mp["mnTrackScaleLevel"][i])
+        r = np.float32(2.5) if float(mp["mTrackViewCos"][i]) > 0.998 else np.float32(4.0)
+        if th != 1.0:
+            r = np.float32(r * np.float32(th))
+        win = np.float32(r * sf[lvl])
+        cands = _py_features_in_area(kps, grid, mp["mTrackProjX"][i], mp["mTrackProjY"][i], win, lvl - 1, lvl)
+        best, best2, bl, bl2, bi = 256, 256, -1, -1, -1
+        for idx in cands:
+            if frame_obs[idx] > 0:
+                continue
+            if u_right is not None and u_right[idx] > 0:
+                if abs(np.float32(mp["mTrackProjXR"][i]) - np.float32(u_right[idx])) > win:
+                    continue
+            dist = _ham(mp["descriptor"][i], desc[idx])
+            if dist < best:
+                best2, best, bl2, bl, bi = best, dist, bl, int(kps["octave"][idx]), idx
+            elif dist < best2:
+                bl2, best2 = int(kps["octave"][idx]), dist
+        if best <= 100:
+            if bl == bl2 and np.float32(best) > np.float32(nnratio) * np.float32(best2):
+                continue
+            frame_match[bi] = i
+            frame_obs[bi] = mp["Observations"][i]
+            match_score[bi] = best
+            nm += 1
+    return nm
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(1, False, 1.0), (2, True, 1.0), (3, True, 3.0), (4, False, 5.0)])
+def test_projection_search_against_python_statement(oracle, seed, stereo, th):
+    rng = np.random.default_rng(100 + seed)
+    kps, desc, _, _ = _random_frames(rng, 400, 1, clusters=8)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    sf = oracle.tables()["scale"]
+    mp = _map_points(rng, kps, desc, 300, sf)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.random(len(kps)).astype(np.float32) * 30, -1).astype(np.float32)
+    obs0 = rng.choice([-1, -1, -1, 0, 2], len(kps)).astype(np.int32)
+    outs = []
+    for fn in ("oracle", "python"):
+        fo, fm, ms = obs0.copy(), np.full(len(kps), -1, np.int32), np.full(len(kps), -1, np.int32)
+        if fn == "oracle":
+            nm = oracle.search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, fo, fm, ms)
+        else:
+            nm = _py_search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, sf, fo, fm, ms)
+        outs.append((nm, fo, fm, ms))
+    assert outs[0][0] == outs[1][0] and outs[0][0] > 30
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert np.array_equal(a, b)
+    # exclusion did matter: fewer keypoints hold a match than matches were counted, or a map point with
+    # observations blocks later ones -- at least one keypoint was claimed by a point with Observations() > 0
+    assert (outs[0][1][outs[0][2] >= 0] > 0).any()
+
+
+def test_projection_search_rules(oracle):
+    sf = oracle.tables()["scale"]
+    kps = _kps([(100, 100), (102, 100), (400, 300)], octave=[1, 1, 1])
+    desc = _desc_with_bits([0, 30, 0])
+
+    def run(mp_bits, obs, frame_obs=(-1, -1, -1), u_right=None, level=1, xr=0.0, ratio=0.8, th=1.0, view_cos=0.9):
+        M = len(mp_bits)
+        mp = {"mbTrackInView": np.ones(M, np.uint8), "isBad": np.zeros(M, np.uint8),
+              "mTrackProjX": np.full(M, 101, np.float32), "mTrackProjY": np.full(M, 100, np.float32),
+              "mTrackProjXR": np.full(M, xr, np.float32), "mnTrackScaleLevel": np.full(M, level, np.int32),
+              "mTrackViewCos": np.full(M, view_cos, np.float32), "Observations": np.array(obs, np.int32),
+              "descriptor": _desc_with_bits(mp_bits)}
+        fo = np.array(frame_obs, np.int32)
+        fm, ms = np.full(3, -1, np.int32), np.full(3, -1, np.int32)
+        nm = oracle.search_by_projection(kps, desc, u_right, GRID, mp, th, ratio, fo, fm, ms)
+        return nm, fo.tolist(), fm.tolist(), ms.tolist()
+
+    # one map point at distance 5 / 25 from the two candidates (same level): 5 <= 0.8 * 25 -> keypoint 0
+    assert run([5], [3]) == (1, [3, -1, -1], [0, -1, -1], [5, -1, -1])
+    # ratio test fails only when both are on the same level: 22 > 0.8 * 8?  dist 22 / 8 -> best 8 (kp 1), second 22
+    assert run([22], [3])[2] == [-1, 0, -1]
+    assert run([16], [3], ratio=0.8)[0] == 0                 # 14 vs 16: 14 > 12.8 -> rejected
+    # a second map point cannot take a keypoint claimed by a point with observations (:197-199) ...
+    assert run([5, 4], [3, 3]) == (2, [3, 3, -1], [0, 1, -1], [5, 26, -1])
+    # ... but overwrites one claimed by a point without observations, and both count (:233-236)
+    assert run([5, 4], [0, 3]) == (2, [3, -1, -1], [1, -1, -1], [4, -1, -1])
+    # a keypoint that already holds a map point with observations is never a candidate
+    assert run([5], [3], frame_obs=(2, -1, -1)) == (1, [2, 3, -1], [-1, 0, -1], [-1, 25, -1])
+    # TH_HIGH = 100 (:228)
+    kps["x"][1] = 300
+    assert run([100], [1])[0] == 1 and run([101], [1])[0] == 0
+    kps["x"][1] = 102
+    # level window [level - 1, level]: candidates on level 1 are seen from predicted levels 1 and 2 only
+    assert run([5], [1], level=2)[0] == 1 and run([5], [1], level=3)[0] == 0 and run([5], [1], level=0)[0] == 0
+    # right-image gate (:201-206): |projXR - uR| > r * scale -> skipped; r = 4 (cos 0.9), scale[1] = 1.2 -> 4.8
+    ur = np.array([80.0, -1.0, -1.0], np.float32)
+    assert run([5], [1], u_right=ur, xr=84.5)[2] == [0, -1, -1]
+    assert run([5], [1], u_right=ur, xr=85.0)[2] == [-1, 0, -1]
+    # radius: 2.5 for cos > 0.998, times th when th != 1
+    kps["x"][0], kps["x"][1] = 97.5, 300
+    assert run([5], [1], view_cos=0.999)[0] == 0             # |97.5 - 101| = 3.5 >= 2.5 * 1.2 = 3.0
+    assert run([5], [1], view_cos=0.9)[0] == 1               # 3.5 < 4.8
+    assert run([5], [1], view_cos=0.999, th=1.5)[0] == 1     # 3.5 < 4.5

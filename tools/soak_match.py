@@ -5,6 +5,7 @@ of the sweep (the library's own choice: FP4 matrix instructions from 64 train de
 every size) against the CPU oracle; best index, best distance and second distance must agree exactly.
 Usage: python tools/soak_match.py [n_cases] [seed]"""
 import os
+os.environ.setdefault("ORBX_SWITCHES_PER_CALL", "1")   # the form switch below is read at every call only then
 import sys
 
 import numpy as np

@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak
+FP4_PEAK_TFLOPS = 10000.0      # dense block-scaled FP4 matrix peak (the brute-force matcher's inner products)
 SIMDS, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies its SIMD for 4 cycles
 
 CONFIGS = {
@@ -65,6 +66,9 @@ def parse():
     ap.add_argument("--single-frame", action="store_true",
                     help="also time orbx_extract on one host frame (adds small launches of every kernel, which\n"
                          "would dilute per-kernel averages in a profile of the default command)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group at world size 1 as well, so that the RCCL initialisation, the barrier, the\n"
+                         "all-reduce and the device-tensor result gather execute on a one-GPU box")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; "
                     "gloo only to rehearse the multi-rank path on a box with fewer GPUs than ranks)")
     return ap.parse_args()
@@ -255,8 +259,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     ndev = torch.cuda.device_count()
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(1, ndev)
-    if world > 1:
+    dist_on = world > 1 or args.force_dist
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # a plain one-rank start
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
@@ -271,12 +283,12 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(x):
-        if world == 1:
+        if not dist_on:
             return x
         t = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -388,6 +400,20 @@ def main():
     ex, B, W, H = wl.ex, wl.B, wl.w, wl.h
     A_bytes, P_pixels = path_bytes(ex, W, H, wl.nfeat)
 
+    # The same W + K steps straight from an idle GPU first (what a run without the settle phase measures: the first
+    # tens of milliseconds of full load after idle run at a lower clock), reported as value_from_idle.
+    wl.step()                                   # first call: buffers are sized here
+    barrier()
+    time.sleep(0.5)
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    idle_elapsed = max_over_ranks(time.perf_counter() - t0)
+
     settle_steps = settle(wl.step, args.settle_ms)
     for _ in range(args.warmup):
         wl.step()
@@ -473,6 +499,10 @@ def main():
         "metric": "ORB frames/sec (752x480, 1000 feat, 8 lvl)" if args.config in ("euroc", "stereo") else
                   "ORB frames/sec (%dx%d, %d feat, 8 lvl)" % (W, H, wl.nfeat),
         "value": round(fps, 1), "unit": "frames/s",
+        "value_from_idle": round(wl.global_frames_per_step * args.steps / idle_elapsed, 1),
+        "value_from_idle_note": "the same %d warm-up + %d timed steps started 0.5 s after the GPU went idle, before the settle "
+                                "phase: `value` is the rate under sustained load, this one includes the clock transient after "
+                                "idle" % (args.warmup, args.steps),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "settle": {"ms": args.settle_ms, "steps": settle_steps,
                    "note": "untimed steps of the same workload before the warm-up, so that the timed steps run at the clock "
@@ -490,7 +520,7 @@ def main():
     }
 
     # ---- multi-rank facts: the world that was really initialised, per-rank rates, the result gather ----
-    if world > 1:
+    if dist_on:
         rates = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
         dist.all_gather(rates, torch.tensor([my_fps], dtype=torch.float64, device=red_dev))
         Fl = len(wl.host)
@@ -528,6 +558,32 @@ def main():
         ex.set_stream(stream.cuda_stream)
         out["invariant"] = "frames 0 and %d of the timed batch are byte-identical to single-frame calls" % (len(wl.host) - 1)
 
+    # ---- the north-star descriptor criterion on the benchmarked frames: this run's GPU output against the CPU
+    #      restatement with the reference's trig formulation (this host's libm cosf / sinf), part of the CPU leg ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_lib import Oracle
+        o_ = Oracle(wl.nfeat, 1.2, 8, 20, 7, native=False, trig="libm")
+        nfr = min(len(wl.host), 32 if args.config != "4k-map" else 2)
+        tot = dif = 0
+        worst = 0.0
+        same_kp = True
+        for i in range(nfr):
+            ko, do = o_.extract(wl.host[i])
+            n_i = int(nkp[i])
+            kg = kb[i, :n_i].view(np.uint8).reshape(n_i, 28).copy().view(KP_DTYPE).reshape(n_i)
+            same_kp = same_kp and n_i == len(ko) and all(np.array_equal(kg[f_], ko[f_]) for f_ in
+                                                         ("x", "y", "size", "response", "octave", "class_id"))
+            if n_i == len(ko):
+                worst = max(worst, float(np.abs(kg["angle"] - ko["angle"]).max(initial=0.0)))
+                dif += int((db[i, :n_i] != do).any(axis=1).sum())
+                tot += n_i
+        out["parity_vs_libm_trig"] = {"frames": nfr, "keypoints": tot, "keypoints_bit_identical": bool(same_kp),
+                                      "max_angle_diff_deg": worst, "descriptors_identical_frac": round(1.0 - dif / max(1, tot), 6),
+                                      "what": "GPU output of the timed batch's first frames against the CPU restatement in its "
+                                              "libm mode (cosf / sinf of this host, as src/ORBextractor.cc:108-109 calls them); "
+                                              "criterion: keypoints identical, angles within 1e-3 deg, >= 0.999 of descriptors identical"}
+
     extras = not args.no_extras and world == 1 and args.config == "euroc"
     frame_sample = None
     # ---- Hamming matching alone: every rank searches its own queries against its replica of the train set;
@@ -543,25 +599,64 @@ def main():
         dq2 = torch.randint(0, 256, (Q2, 32), dtype=torch.uint8, generator=g).to(dev)
         dt2 = torch.randint(0, 256, (T2, 32), dtype=torch.uint8, generator=g).to(dev)
         outs2 = [torch.zeros((Q2,), dtype=torch.int32, device=dev) for _ in range(3)]
+        nb8 = 8
+        dq8 = torch.randint(0, 256, (nb8, Q2, 32), dtype=torch.uint8, generator=g).to(dev)
+        outs8 = [torch.zeros((nb8, Q2), dtype=torch.int32, device=dev) for _ in range(3)]
+        try:
+            mprof = json.load(open(os.path.join(ROOT, "profiles", "match_issue.json")))
+        except Exception:
+            mprof = {}
         res = {}
-        for name, fn, pairs, nq in (
-                ("stereo_128x1000x1000", lambda: m.match_bruteforce_device(dq, Q, Q, None, dt, Q, Q, None, nb, *outs), nb * Q * Q, nb * Q),
-                ("map_8000x100000", lambda: m.match_bruteforce_device(dq2, Q2, Q2, None, dt2, T2, T2, None, 1, *outs2), Q2 * T2, Q2),
+        for name, fn, pairs, nq, nt in (
+                ("stereo_128x1000x1000", lambda: m.match_bruteforce_device(dq, Q, Q, None, dt, Q, Q, None, nb, *outs), nb * Q * Q, nb * Q, nb * Q),
+                ("map_8000x100000", lambda: m.match_bruteforce_device(dq2, Q2, Q2, None, dt2, T2, T2, None, 1, *outs2), Q2 * T2, Q2, T2),
                 # one ordinary frame's features against the same map (the first 1000 queries of the set above)
-                ("frame_1000x100000", lambda: m.match_bruteforce_device(dq2, Q, Q, None, dt2, T2, T2, None, 1, *outs2), Q * T2, Q)):
+                ("frame_1000x100000", lambda: m.match_bruteforce_device(dq2, Q, Q, None, dt2, T2, T2, None, 1, *outs2), Q * T2, Q, T2),
+                # the matching half of config 4k-map: 8 frames of 8000 queries against one shared 100 000-point map
+                ("map_8x8000x100000", lambda: m.match_bruteforce_device(dq8, Q2, Q2, None, dt2, T2, 0, None, nb8, *outs8),
+                 nb8 * Q2 * T2, nb8 * Q2, T2)):
             settle(fn, args.settle_ms / 2)
             for _ in range(3):
                 fn()
             barrier()
             reps = 20
+            # HIP events on the stream the kernels run on (torch's current stream is the library's stream here)
             t0 = time.perf_counter()
             for _ in range(reps):
                 fn()
             barrier()
             dt_ = time.perf_counter() - t0
             dt_ = max_over_ranks(dt_)
+            # the kernel time on its own, after the timed calls (an event pair per call costs a few microseconds of its own)
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in evs:
+                e0.record()
+                fn()
+                e1.record()
+            barrier()
+            call_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
+            tflops = pairs * 512 / (call_ms * 1e-3) / 1e12          # 256 multiply-adds per pair of 256-bit descriptors
+            formal = 32 * (nq + nt) + 12 * nq
+            roof = {"bound": "mfma", "kernel": "k_match_bruteforce_fp4 (+ k_match_merge)", "achieved": round(tflops, 1),
+                    "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP4_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel_ms": round(call_ms, 4),
+                    "flops_note": "pair distances x 512 (256-bit inner product as block-scaled FP4 matrix instructions) against the "
+                                  "dense FP4 peak; kernel_ms = HIP events around the call's launches on their stream",
+                    "hbm_formal": {"bytes_per_call": formal, "GB/s": round(formal / (call_ms * 1e-3) / 1e9, 2),
+                                   "frac_of_hbm_peak": round(formal / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                   "note": "32 (Q + T) + 12 Q bytes: every descriptor read once, three results per query"}}
+            pm = mprof.get(name)
+            if pm:
+                roof["valu_issue_frac"] = round(pm["SQ_INSTS_VALU"] * 4 / (SIMDS * call_ms * 1e-3 * CLOCK_GHZ * 1e9), 4)
+                roof["mfma_busy_frac"] = round(pm["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * call_ms * 1e-3 * CLOCK_GHZ * 1e9), 4) \
+                    if "SQ_VALU_MFMA_BUSY_CYCLES" in pm else None
+                if pm.get("SQ_LDS_IDX_ACTIVE"):
+                    roof["lds_conflict_frac"] = round(pm["SQ_LDS_BANK_CONFLICT"] / pm["SQ_LDS_IDX_ACTIVE"], 4)
+                roof["counters_source"] = "profiles/match_issue.json (rocprofv3 --pmc passes of tools/match_one_shape.py, the same " \
+                                          "shape; per-launch counters, not measured in this run) over this run's kernel time"
             res[name] = {"pair_distances_per_s": round(world * pairs * reps / dt_, 1),
-                         "queries_per_s": round(world * nq * reps / dt_, 1), "ms_per_call": round(dt_ / reps * 1e3, 4)}
+                         "queries_per_s": round(world * nq * reps / dt_, 1), "ms_per_call": round(dt_ / reps * 1e3, 4),
+                         "roofline": roof}
             if world > 1:
                 res[name]["note"] = "whole job: %d ranks, each its own %d queries against a replicated train set" % (world, nq)
         out["hamming"] = res
@@ -670,7 +765,7 @@ def main():
         out["cpu_baseline"] = None
 
     wl.close()
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

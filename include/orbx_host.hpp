@@ -11,7 +11,9 @@
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
+#include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "orbx.h"
@@ -116,6 +118,67 @@ private:
     int iniThFAST_, minThFAST_;
     std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
     std::vector<int32_t> mnFeaturesPerLevel;
+};
+
+// Several GPUs in one process: one extractor (context + stream) per listed device, one host thread per
+// extractor during a call -- the pattern of the reference's stereo Frame constructor, which runs its left and right
+// extractor on two threads (src/Frame.cc:84-87), widened from 2 cameras to G devices.  Frames are independent, so a
+// batch is cut into contiguous frame ranges [g*B/G, (g+1)*B/G) and every shard writes straight into the caller's
+// arrays at its frames' places: results arrive in frame order and are identical to one extractor running the whole
+// batch.  No collective is involved (one process, host memory).  A device may be listed more than once (two
+// contexts on one GPU overlap their transfers and kernels).
+class ShardedExtractor {
+public:
+    ShardedExtractor(const std::vector<int>& devices, int nfeatures, float scaleFactor, int nlevels, int iniThFAST,
+                     int minThFAST)
+    {
+        if (devices.empty()) throw std::invalid_argument("ShardedExtractor needs at least one device");
+        for (int d : devices)
+            shards_.emplace_back(new ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, d));
+        for (auto& e : shards_) e->mirrorPyramid = false;
+    }
+
+    int shards() const { return (int)shards_.size(); }
+    ORBextractor& shard(int g) { return *shards_[g]; }
+    // frames [first, last) of shard g of a batch of nframes
+    static void frame_range(int g, int nshards, int nframes, int& first, int& last)
+    {
+        first = (int)((long long)g * nframes / nshards);
+        last = (int)((long long)(g + 1) * nframes / nshards);
+    }
+    int max_keypoints(int w, int h)
+    {
+        int cap = 0;
+        if (orbx_max_keypoints(shards_[0]->context(), w, h, &cap) != ORBX_OK)
+            throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(shards_[0]->context()));
+        return cap;
+    }
+
+    // nframes frames of one size (imgs[f]: `stride` bytes per row) -> kps[nframes * cap], desc[nframes * cap * 32],
+    // n_out[nframes], the layout of orbx_extract_batch.  Throws the first shard's error after all shards have finished.
+    void ExtractBatch(const uint8_t* const* imgs, int nframes, int w, int h, int stride, orbx_keypoint* kps, uint8_t* desc,
+                      int cap, int32_t* n_out)
+    {
+        const int G = shards();
+        std::vector<int> rc(G, ORBX_OK);
+        std::vector<std::thread> th;
+        auto work = [&](int g) {
+            int f0, f1;
+            frame_range(g, G, nframes, f0, f1);
+            if (f1 > f0)
+                rc[g] = orbx_extract_batch(shards_[g]->context(), imgs + f0, f1 - f0, w, h, stride, kps + (size_t)f0 * cap,
+                                           desc + (size_t)f0 * cap * 32, cap, n_out + f0);
+        };
+        for (int g = 1; g < G; g++) th.emplace_back(work, g);
+        work(0);                                   // the calling thread is shard 0's
+        for (auto& t : th) t.join();
+        for (int g = 0; g < G; g++)
+            if (rc[g] != ORBX_OK)
+                throw std::runtime_error("liborbx (shard " + std::to_string(g) + "): " + orbx_last_error(shards_[g]->context()));
+    }
+
+private:
+    std::vector<std::unique_ptr<ORBextractor>> shards_;
 };
 
 // Frame::UndistortKeyPoints (src/Frame.cc:818-852) and each half of UndistortKeyPointsStereo

@@ -77,8 +77,9 @@ def test_cpp_host_class_builds_against_the_abi():
     with plain g++ and links against liborbx.so."""
     import subprocess
     d = os.path.join(ROOT, "tests", "cpp")
-    subprocess.check_call(["make", "-C", d, "host_extract", "stereo_delayed"])
-    assert os.path.exists(os.path.join(d, "host_extract")) and os.path.exists(os.path.join(d, "stereo_delayed"))
+    subprocess.check_call(["make", "-C", d, "host_extract", "stereo_delayed", "sharded_extract"])
+    for exe in ("host_extract", "stereo_delayed", "sharded_extract"):
+        assert os.path.exists(os.path.join(d, exe))
 
 
 def test_adapter_header_compiles_against_cv_stand_in():

@@ -378,6 +378,38 @@ def test_cpp_host_program(oracle, euroc_left, tmp_path):
     assert buf[-1] == top[top.shape[0] // 2, top.shape[1] // 2]
 
 
+def test_cpp_sharded_extractor_and_matcher(oracle, euroc_left, euroc_right, tmp_path):
+    """orbx::ShardedExtractor (one context + host thread per listed device, contiguous frame ranges, results in the
+    caller's arrays in frame order) equals a single context on every frame -- three shards on the one GPU of the
+    test box, 7 frames, so the shards get 2, 2 and 3 -- and orbx::ORBmatcher::SearchForInitialization on the first
+    two frames equals the oracle's."""
+    import os
+    import subprocess
+    from orb_slam_amd.synth import synthetic_batch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "sharded_extract")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "sharded_extract"])
+    frames = np.concatenate([np.stack([euroc_left, euroc_right]), synthetic_batch(5, 752, 480, seed0=8800)])
+    raw = tmp_path / "frames.raw"
+    out = tmp_path / "init.bin"
+    frames.tofile(raw)
+    p = subprocess.run([exe, str(raw), "752", "480", str(len(frames)), "0,0,0", str(out)], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=150)
+    assert p.returncode == 0, p.stderr.decode()
+    assert "sharded ok: 7 frames over 3 shards" in p.stdout.decode()
+    k1, d1 = oracle.extract(euroc_left)
+    k2, d2 = oracle.extract(euroc_right)
+    prev = np.stack([k1["x"], k1["y"]], 1).astype(np.float32)
+    grid = (0.0, 0.0, float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480)))
+    nm_o, m_o = oracle.search_for_initialization(k1, d1, k2, d2, grid, prev, 100, 0.9, True)
+    buf = out.read_bytes()
+    n1, nm = np.frombuffer(buf, np.int32, 2)
+    assert n1 == len(k1) and nm == nm_o and nm > 20
+    assert np.array_equal(np.frombuffer(buf, np.int32, n1, 8), m_o)
+    assert np.array_equal(np.frombuffer(buf, np.float32, 2 * n1, 8 + 4 * n1).reshape(n1, 2), prev)
+
+
 def test_cpp_adapter_program(euroc_left, tmp_path):
     """The drop-in class of include/orbx_adapter.hpp, driven like the reference's Frame drives its extractors:
     same keypoints / descriptors as the OpenCV-free host class, level views that are regions of interest inside

@@ -2,7 +2,7 @@
 # Copies the summaries of gpurun_out/prof_<tag> (tools/profile_round.sh) into profiles/ under the round's name.
 # Usage: bash tools/collect_profiles.sh <tag>
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 P=gpurun_out/prof_$TAG
 cp $P/stats/bench_kernel_stats.csv profiles/${TAG}_bench_kernel_stats.csv
 cp $P/stats_headline/bench_kernel_stats.csv profiles/${TAG}_bench_headline_only_kernel_stats.csv
@@ -20,4 +20,5 @@ cp $P/pmc_match_per_launch.txt profiles/${TAG}_pmc_match_per_launch.txt
 cp $P/pmc_match_fp4_8x8000x100000.txt profiles/${TAG}_pmc_match_fp4_8x8000x100000.txt
 cp $P/traffic.json profiles/traffic.json
 cp $P/issue.json profiles/issue.json
+cp $P/match_issue.json profiles/match_issue.json
 ls -la profiles

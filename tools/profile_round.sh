@@ -5,7 +5,7 @@
 # workload alone, the counter passes (each its own short run) and their per-launch summaries;
 # tools/make_traffic.py / tools/make_issue.py turn the counter files into profiles/traffic.json / issue.json.
 set -e -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -38,5 +38,6 @@ python3 tools/pmc_summary.py $(find $OUT/pmc_sq1 $OUT/pmc_sq2 $OUT/pmc_tcp -name
 python3 tools/pmc_summary.py $(find $OUT/pmc_fetch $OUT/pmc_write -name '*counter_collection.csv') > $OUT/pmc_fetch_write_per_launch.txt
 python3 tools/make_traffic.py $(find $OUT/pmc_fetch -name '*counter_collection.csv') $(find $OUT/pmc_write -name '*counter_collection.csv') $OUT/traffic.json > /dev/null
 python3 tools/make_issue.py $(find $OUT/pmc_sq1 -name '*counter_collection.csv') $OUT/issue.json > /dev/null
+python3 tools/make_match_issue.py $(find $OUT/pmc_fp4a $OUT/pmc_fp4b -name '*counter_collection.csv') $OUT/match_issue.json > /dev/null
 python3 tools/trace_filter.py $(find $OUT/stats -name '*kernel_trace.csv') k_fast_blur > $OUT/fast_blur_headline_shape_in_default_run.txt
 ls -R $OUT | head -80

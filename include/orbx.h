@@ -92,7 +92,15 @@ int orbx_extract_batch(orbx_ctx *ctx, const uint8_t *const *imgs, int nframes, i
  * context's stream, no host synchronisation.  d_imgs: nframes frames,
  * `stride` bytes per row, `frame_stride` bytes between frames.  A frame that
  * yields more than cap_per_frame keypoints stores the first cap_per_frame and
- * reports the full count in d_n_out. */
+ * reports the full count in d_n_out.
+ * When d_imgs, stride, frame_stride and w are multiples of 4 (and the image is at least 64 x 64) the
+ * kernels read pyramid level 0 from d_imgs itself instead of copying it first (the reference's
+ * copyMakeBorder of level 0, src/ORBextractor.cc:1212-1213, is then made only on demand).  Lifetime rule
+ * that follows: a caller who goes on to read level 0 of this context's pyramid -- orbx_pyramid_level, or
+ * orbx_stereo_match_sad[_device] with this context -- keeps d_imgs unchanged until that call has run;
+ * a caller who reads neither may reuse the buffer as soon as the stream has passed this call.  The
+ * host-buffer entry points (orbx_extract, orbx_extract_batch, orbx_compute_pyramid) hold their own copy
+ * of the image and carry no such rule. */
 int orbx_extract_batch_device(orbx_ctx *ctx, const uint8_t *d_imgs, int nframes, int w, int h,
                               int stride, size_t frame_stride, orbx_keypoint *d_kps, uint8_t *d_desc,
                               int cap_per_frame, int32_t *d_n_out);

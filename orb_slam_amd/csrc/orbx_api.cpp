@@ -77,6 +77,14 @@ struct orbx_ctx {
     size_t pin_cap = 0, pin_used = 0;
     std::vector<PinPending> pin_pending;
     DevBuf xtab, ytab, xtab4, ytab2, fast_cells;
+    // Level 0 straight from the caller's image (RawL0, orbx_kernels.hpp): the tables that depend on the image's row
+    // stride, built from these host copies when a stride is first seen; and the image the level-0 plane of the
+    // pyramid block is still owed from (filled in by materialise_level0 when somebody reads that plane).
+    std::vector<FastCell> h_cells0;
+    std::vector<YTab2> h_ytab2_l1;
+    DevBuf raw_cells0, raw_ytab2;
+    int raw_stride = -1;
+    struct Level0Owed { const uint8_t* img = nullptr; int stride = 0, nframes = 0; size_t frame_stride = 0; } l0_owed;
 
     // per-batch working set
     int cap_frames = 0;
@@ -200,6 +208,15 @@ int ensure_geometry(orbx_ctx* c, int w, int h)
         HIPCHECK(c, hipMemcpyAsync(c->fast_cells.p, rt.fast_cells.data(), rt.fast_cells.size() * sizeof(FastCell), hipMemcpyHostToDevice, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));   // the tables are stack-owned
     c->g = g;
+    {   // what the stride-dependent tables of RawL0 are made from: level 0's FAST cells, level 1's row table
+        const int n0 = g.lv[0].width > 0 ? g.lv[0].nCols * g.lv[0].nRows : 0;
+        c->h_cells0.assign(rt.fast_cells.begin(), rt.fast_cells.begin() + n0);
+        c->h_ytab2_l1.clear();
+        if (g.nlevels > 1 && g.resize_slide_ok)
+            c->h_ytab2_l1.assign(rt.ytab2.begin() + g.lv[1].ytab2_off, rt.ytab2.begin() + g.lv[1].ytab2_off + g.lv[1].rows);
+        c->raw_stride = -1;
+        c->l0_owed = orbx_ctx::Level0Owed{};
+    }
     // short bands: the kernel is bound by the latency of its dependent row groups, and many short
     // wavefronts hide it better than few long ones (measured optimum 12 rows, 6 of warm-up included)
     make_slide_map(c->g, getenv("ORBX_BLUR_ROWS") ? atoi(getenv("ORBX_BLUR_ROWS")) : 12, c->blur_map);
@@ -243,13 +260,62 @@ int ensure_frames(orbx_ctx* c, int nframes)
 // the launch sequence; everything asynchronous on c->stream
 // f0: index of the first of these frames inside the context's per-frame buffers (a batch fed from the
 // host runs in chunks; the caller has sized the buffers for all of them before the first chunk)
+// src_on_device: d_imgs is device memory (a resident batch, or the upload buffer of a host-fed one): level 0 can then be
+// read where it lies.  Page-locked host memory the device reads over the bus is copied into the pyramid block once instead.
 int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int stride, size_t frame_stride,
-              orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out, bool pyramid_only, int f0 = 0)
+              orbx_keypoint* d_kps, uint8_t* d_desc, int cap, int32_t* d_n_out, bool pyramid_only, int f0 = 0,
+              bool src_on_device = false)
 {
     int rc = ensure_geometry(c, w, h);
     if (rc != ORBX_OK) return rc;
     rc = ensure_frames(c, f0 + nframes);
     if (rc != ORBX_OK) return rc;
+    RawL0 raw;
+    {
+        // ORBX_NO_RAW0: always copy level 0 into the pyramid block (read once; at every call in a process started with
+        // ORBX_SWITCHES_PER_CALL, as the tests are)
+        static const bool per_call = getenv("ORBX_SWITCHES_PER_CALL") != nullptr;
+        static const bool no_raw_at_start = getenv("ORBX_NO_RAW0") != nullptr;
+        const bool no_raw = per_call ? getenv("ORBX_NO_RAW0") != nullptr : no_raw_at_start;
+        const FrameGeom& g0 = c->g;
+        const bool aligned = (((uintptr_t)d_imgs | (uintptr_t)frame_stride | (uintptr_t)stride | (uintptr_t)w) & 3u) == 0;
+        // every consumer of level 0 has its image form only on the ordinary path: sliding-window resize, some FAST cells
+        // on level 0, an image tall and wide enough for a single reflection, offsets that fit 32 bits and 16 bits
+        if (src_on_device && !no_raw && !pyramid_only && aligned && g0.resize_slide_ok && g0.nlevels > 1 && !c->h_cells0.empty() &&
+            w >= 64 && h >= 64 && stride <= 65532 && (size_t)stride * (size_t)h < ((size_t)1 << 31)) {
+            if (c->raw_stride != stride) {
+                // the tables addressed into an image with this row stride (plane offsets -> image offsets)
+                const LevelGeom& L0 = g0.lv[0];
+                std::vector<FastCell> cells = c->h_cells0;
+                for (FastCell& fc : cells) {
+                    if (fc.cw == 0) continue;
+                    const uint32_t rel = fc.src_off - L0.plane_off;
+                    const uint32_t prow = rel / (uint32_t)L0.pitch, pcol = rel - prow * (uint32_t)L0.pitch;
+                    fc.src_off = (prow - (uint32_t)kPadY) * (uint32_t)stride + (pcol - (uint32_t)kPadX);
+                    fc.pitch = (uint16_t)stride;
+                }
+                std::vector<YTab2> yt = c->h_ytab2_l1;
+                for (YTab2& y : yt) {
+                    y.off0 = ((y.off0 - (uint32_t)kPadX) / (uint32_t)L0.pitch - (uint32_t)kPadY) * (uint32_t)stride;
+                    y.off1 = ((y.off1 - (uint32_t)kPadX) / (uint32_t)L0.pitch - (uint32_t)kPadY) * (uint32_t)stride;
+                }
+                HIPCHECK(c, hipStreamSynchronize(c->stream));          // earlier launches may still read the old tables
+                HIPCHECK(c, c->raw_cells0.ensure(cells.size() * sizeof(FastCell) + 32));
+                HIPCHECK(c, c->raw_ytab2.ensure(yt.size() * sizeof(YTab2)));
+                HIPCHECK(c, hipMemcpy(c->raw_cells0.p, cells.data(), cells.size() * sizeof(FastCell), hipMemcpyHostToDevice));
+                HIPCHECK(c, hipMemcpy(c->raw_ytab2.p, yt.data(), yt.size() * sizeof(YTab2), hipMemcpyHostToDevice));
+                c->raw_stride = stride;
+            }
+            raw.base = d_imgs;
+            raw.cells0 = c->raw_cells0.as<FastCell>();
+            raw.ytab2_l1 = c->raw_ytab2.as<YTab2>();
+            raw.frame_stride = frame_stride;
+            raw.frame_bytes = (uint32_t)((size_t)stride * (size_t)h);
+            raw.stride = stride;
+            raw.ncells0 = (int)c->h_cells0.size();
+            raw.on = 1;
+        }
+    }
     const FrameGeom& g = c->g;
     const size_t F = (size_t)f0;
     uint8_t* const pyr = c->pyr.as<uint8_t>() + F * g.pyr_frame_bytes;
@@ -280,13 +346,23 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     auto t1 = [&](int i, hipStream_t q) { if (es && (!only_fast || i == ST_FAST)) (void)hipEventRecord(es->stop[i], q); };
 
     t0(ST_PYR0, s);
-    launch_pyr_level0(d_imgs, stride, frame_stride, pyr, g, nframes, s);
+    if (raw.on) {
+        // nobody on this path reads the level-0 plane; whoever asks for it later (orbx_pyramid_level, the classic stereo
+        // search) gets it from the image, which the caller keeps until then (chunks of one batch are contiguous)
+        c->l0_owed.img = d_imgs - F * frame_stride;
+        c->l0_owed.stride = stride;
+        c->l0_owed.frame_stride = frame_stride;
+        c->l0_owed.nframes = f0 + nframes;
+    } else {
+        if (f0 == 0) c->l0_owed = orbx_ctx::Level0Owed{};
+        launch_pyr_level0(d_imgs, stride, frame_stride, pyr, g, nframes, s);
+    }
     t1(ST_PYR0, s);
     t0(ST_RESIZE, s);
     static const bool old_resize = getenv("ORBX_OLD_RESIZE") != nullptr;
     const bool slide = g.resize_slide_ok && !old_resize;
     for (int l = 1; l < g.nlevels; l++) {
-        if (slide) launch_resize_slide(pyr, g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s);
+        if (slide) launch_resize_slide(pyr, g, l, c->xtab4.as<XTab4>(), c->ytab2.as<YTab2>(), nframes, s, l == 1 ? raw : RawL0());
         else launch_pyr_resize(pyr, g, l, c->xtab.as<XTab>(), c->ytab.as<YTab>(), nframes, s);
     }
     t1(ST_RESIZE, s);
@@ -306,9 +382,9 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     t0(ST_FAST, s);
     if (fused)
         launch_fast_blur(pyr, blur, g, c->fast_lds, nframes >= 32 ? c->blur_map_batch : c->blur_map, c->fast_cells.as<FastCell>(),
-                         cell_cand, cell_count, nframes, s);
+                         cell_cand, cell_count, nframes, s, raw);
     else
-        launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s);
+        launch_fast_cells_wave(pyr, g, c->fast_lds, c->fast_cells.as<FastCell>(), cell_cand, cell_count, nframes, s, raw);
     t1(ST_FAST, s);
     // The blur only feeds the descriptors and the quadtree is a chain of workgroup barriers that
     // leaves the memory system idle, so the two run side by side on two streams (ORBX_OVERLAP=0
@@ -319,7 +395,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         HIPCHECK(c, hipStreamWaitEvent(bs, c->ev_pyr, 0));
     }
     t0(ST_BLUR, bs);
-    if (!fused) launch_blur_slide(pyr, blur, g, c->blur_map, nframes, bs);
+    if (!fused) launch_blur_slide(pyr, blur, g, c->blur_map, nframes, bs, raw);
     t1(ST_BLUR, bs);
     if (overlap) HIPCHECK(c, hipEventRecord(c->ev_blur, bs));
     t0(ST_QUADTREE, s);
@@ -339,11 +415,24 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
     t1(ST_QUADTREE, s);
     if (overlap) HIPCHECK(c, hipStreamWaitEvent(s, c->ev_blur, 0));
     t0(ST_DESC, s);
-    launch_orient_desc(g, pyr, blur, kp_stage, level_count, d_kps, d_desc, cap, d_n_out, nframes, s);
+    launch_orient_desc(g, pyr, blur, kp_stage, level_count, d_kps, d_desc, cap, d_n_out, nframes, s, raw);
     t1(ST_DESC, s);
     if (es) es->pending = true;
     HIPCHECK(c, hipGetLastError());
     c->have_features = true;
+    return ORBX_OK;
+}
+
+// The level-0 plane of the pyramid block, when the last extraction read level 0 from the image instead of copying it:
+// made now, from that image, for a caller that reads the plane (ORBextractor::mvImagePyramid[0], the SAD windows of the
+// classic stereo search).
+int materialise_level0(orbx_ctx* c)
+{
+    if (!c->l0_owed.img) return ORBX_OK;
+    launch_pyr_level0(c->l0_owed.img, c->l0_owed.stride, c->l0_owed.frame_stride, c->pyr.as<uint8_t>(), c->g, c->l0_owed.nframes,
+                      c->stream);
+    HIPCHECK(c, hipGetLastError());
+    c->l0_owed = orbx_ctx::Level0Owed{};
     return ORBX_OK;
 }
 
@@ -614,7 +703,7 @@ void orbx_destroy(orbx_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)finish(c);
-    DevBuf* bufs[] = {&c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
+    DevBuf* bufs[] = {&c->raw_cells0, &c->raw_ytab2, &c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->qt_scratch, &c->qt_counts, &c->in, &c->out_kps,
                       &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
@@ -705,7 +794,7 @@ int orbx_extract_batch_device(orbx_ctx* c, const uint8_t* d_imgs, int nframes, i
     if (!d_imgs || !d_kps || !d_desc || !d_n_out || cap_per_frame < 1) return fail(c, ORBX_ERR_INVALID, "null buffer or cap < 1");
     if (frame_stride < (size_t)stride * (size_t)h) return fail(c, ORBX_ERR_INVALID, "frame_stride smaller than one frame");
     HIPCHECK(c, hipSetDevice(c->device));
-    return run_batch(c, d_imgs, nframes, w, h, stride, frame_stride, d_kps, d_desc, cap_per_frame, d_n_out, false);
+    return run_batch(c, d_imgs, nframes, w, h, stride, frame_stride, d_kps, d_desc, cap_per_frame, d_n_out, false, 0, true);
 }
 
 int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int w, int h, int stride,
@@ -812,13 +901,13 @@ int orbx_extract_batch(orbx_ctx* c, const uint8_t* const* imgs, int nframes, int
             rc = run_batch(c, c->in.as<uint8_t>() + (size_t)f0 * fbytes, m, w, h, w, fbytes,
                            c->out_kps.as<orbx_keypoint>() + (size_t)f0 * cap_per_frame,
                            c->out_desc.as<uint8_t>() + (size_t)f0 * cap_per_frame * 32, cap_per_frame,
-                           c->out_n.as<int32_t>() + f0, false, f0);
+                           c->out_n.as<int32_t>() + f0, false, f0, true);
             if (rc != ORBX_OK) return rc;
         }
     } else {
         HIPCHECK(c, upload(0, nframes, c->stream));
         rc = run_batch(c, c->in.as<uint8_t>(), nframes, w, h, w, fbytes, c->out_kps.as<orbx_keypoint>(),
-                       c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false);
+                       c->out_desc.as<uint8_t>(), cap_per_frame, c->out_n.as<int32_t>(), false, 0, true);
         if (rc != ORBX_OK) return rc;
     }
     HIPCHECK(c, d2h(c, n_out, c->out_n.p, n * 4));
@@ -865,6 +954,10 @@ int orbx_pyramid_level(orbx_ctx* c, int frame, int level, const uint8_t** data, 
     if (frame < 0 || frame >= c->last_nframes || level < 0 || level >= c->g.nlevels)
         return fail(c, ORBX_ERR_INVALID, "frame or level out of range");
     HIPCHECK(c, hipSetDevice(c->device));
+    {
+        const int rc0 = materialise_level0(c);
+        if (rc0 != ORBX_OK) return rc0;
+    }
     if (c->h_pyr_frame != frame) {
         // the mirror is pinned memory of its own: one direct copy, nothing staged
         if (c->h_pyr_bytes < c->g.pyr_frame_bytes) {
@@ -1335,6 +1428,11 @@ int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* 
     if (nbatch > c->last_nframes || nbatch > r->last_nframes) return fail(c, ORBX_ERR_INVALID, "more pairs than frames in the pyramids");
     if (c->g.lv[0].h > 32767) return fail(c, ORBX_ERR_UNSUPPORTED, "image taller than 32767 rows");
     HIPCHECK(c, hipSetDevice(c->device));
+    {   // the SAD windows read level-0 planes too
+        int rc0 = materialise_level0(c);
+        if (rc0 == ORBX_OK) rc0 = materialise_level0(r);
+        if (rc0 != ORBX_OK) return rc0;
+    }
     if (r->stream != c->stream) {   // the right pyramid must be complete before the left stream reads it
         if (!c->ev_pyr) return fail(c, ORBX_ERR_HIP, "no event available");
         HIPCHECK(c, hipEventRecord(c->ev_pyr, r->stream));

@@ -147,9 +147,14 @@ __device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint
     return __builtin_amdgcn_udot2(__builtin_bit_cast(ushort2_t, pq), __builtin_bit_cast(ushort2_t, a01), 0u, false) >> 4;
 }
 
-// rows [r0, r1) of destination dword column dwc of level L, from level P of the same frame
-__device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, const LevelGeom& P,
-                                            const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
+// rows [r0, r1) of destination dword column dwc of level L of one frame.  src + yt[row].off0 / off1 = column 0 of the two
+// source rows: the previous level's plane in the same pyramid block, or (RAW, level 1 only) the caller's image itself,
+// read through a buffer descriptor that covers exactly the frame (the 12-byte windows of the last columns run a few
+// bytes past their row, which at the end of the last row would be past the caller's buffer: such bytes read as zero
+// and carry no weight).
+template <bool RAW>
+__device__ __forceinline__ void resize_band(uint8_t* frame, const uint8_t* src, uint32_t src_bytes, const LevelGeom& L,
+                                            const XTab4* __restrict__ xtab, const YTab2* __restrict__ yt,
                                             int dwc, int r0, int r1, int mirror)
 {
     const XTab4 x = xtab[L.xtab4_off + dwc];
@@ -159,11 +164,18 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
     const uint32_t shx = x.base & 3u;
     // addresses = wave-uniform row pointer + the lane's 32-bit offset: the form a global load / store
     // takes as scalar base + vector offset, with no 64-bit vector arithmetic per access
-    const uint8_t* src = frame + P.plane_off;
     uint8_t* dst = frame + L.plane_off;
     const uint32_t xoff = x.base & ~3u, doff = 4u * (uint32_t)dwc;
-    const YTab2* yt = ytab + L.ytab2_off;
     const int rlast = L.rows - 1;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, RAW ? (int)src_bytes : 0, 0x00020000);
+    auto load12 = [&](uint32_t row_off) -> Aligned12 {
+        if (RAW) {
+            typedef unsigned int v3u_t __attribute__((ext_vector_type(3)));
+            const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)xoff, (int)row_off, 0);
+            return Aligned12{v.x, v.y, v.z};
+        }
+        return *reinterpret_cast<const Aligned12*>(src + (size_t)(uint32_t)(row_off + xoff));
+    };
     // Groups of 4 rows, all loads issued before the arithmetic; a group that runs past the plane
     // repeats its last row (same bytes written again).  Successive destination rows mostly share
     // a source row (the second one of row r is the first one of row r+1 five times out of six at
@@ -184,8 +196,8 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (fresh[k]) t0[k] = *reinterpret_cast<const Aligned12*>(src + (size_t)(uint32_t)(y[k].off0 + xoff));
-            t1[k] = *reinterpret_cast<const Aligned12*>(src + (size_t)(uint32_t)(y[k].off1 + xoff));
+            if (fresh[k]) t0[k] = load12(y[k].off0);
+            t1[k] = load12(y[k].off1);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -230,7 +242,7 @@ __device__ __forceinline__ void resize_band(uint8_t* frame, const LevelGeom& L, 
 
 __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr, FrameGeom g, int level,
                                                       const XTab4* __restrict__ xtab, const YTab2* __restrict__ ytab,
-                                                      int rows_per_band, int ncb, int mirror)
+                                                      int rows_per_band, int ncb, int mirror, RawL0 raw)
 {
     const LevelGeom& L = g.lv[level];
     const int lane = threadIdx.x & 63;
@@ -244,7 +256,11 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
     // that the row table comes in through scalar loads instead of one vector load per lane
     const int r0 = __builtin_amdgcn_readfirstlane(row_lo + rb * rows_per_band), r1 = min(r0 + rows_per_band, row_hi);
     if (dwc * 4 >= L.pitch || r0 >= row_hi) return;
-    resize_band(pyr + (size_t)blockIdx.y * g.pyr_frame_bytes, L, g.lv[level - 1], xtab, ytab, dwc, r0, r1, mirror);
+    uint8_t* frame = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes;
+    if (raw.on && level == 1)
+        resize_band<true>(frame, raw.base + (size_t)blockIdx.y * raw.frame_stride, raw.frame_bytes, L, xtab, raw.ytab2_l1, dwc, r0, r1, mirror);
+    else
+        resize_band<false>(frame, frame + g.lv[level - 1].plane_off, 0u, L, xtab, ytab + L.ytab2_off, dwc, r0, r1, mirror);
 }
 
 // ---------------------------------------------------------------------------
@@ -297,61 +313,36 @@ __device__ __forceinline__ uint32_t blur_vsum(uint32_t h0, uint32_t h1, uint32_t
     return acc > 255u ? 255u : acc;
 }
 
-// one work item (level, 64-dword column block, row band) on one wavefront; item and frame are wave-uniform
-__device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                          const FrameGeom& g, const SlideMap& sm, int item, int lane, int frame)
+// The rows of one lane's band.  Source row nb + p (row 0 is image row y0 - 3; nb is the same for the six rows of a
+// group, p a compile-time constant) of the lane's three dwords comes through `load3`; the destination is the blurred plane.
+// Branch-free schedule: 6 warm-up rows, then groups of 6 rows whose loads are all issued
+// before the arithmetic.  A band's last group may run past the band (at most 5 rows): those
+// rows are read from the stored border (or reflected, when the source is the caller's image) and written with the
+// same values the next band writes (or into the unused border of the blurred plane).
+// Column pass: the horizontal sums of rows t-1 and t are kept as one packed pair
+// P[t % 6] = h(t-1) | h(t) << 16, so that output row n-6 (taps = rows n-6 .. n) is three
+// 2-term dot products over the pairs of times n-5, n-3, n-1 plus the tap of row n.
+template <class Load3>
+__device__ __forceinline__ void blur_band(Load3 load3, uint8_t* __restrict__ dst, uint32_t doff, uint32_t dpitch, int nrows)
 {
-    if (item >= sm.base[kMaxLevels]) return;
-    int level = 0;
-#pragma unroll
-    for (int l = 1; l < kMaxLevels; l++)
-        if (l < g.nlevels && item >= sm.base[l]) level = l;
-    const LevelGeom& L = g.lv[level];
-    // the level's (band, dword column) pairs are dealt to lanes in one flat sequence, so only the
-    // last wavefront of a level has idle lanes
-    const int flat = (item - sm.base[level]) * 64 + lane;
-    const int ndw = sm.ndw[level];
-    if (flat >= ndw * sm.nrb[level]) return;
-    const int rb = ndw == 1 ? flat : (int)__umulhi((uint32_t)flat, sm.rcp_ndw[level]);   // band
-    const int dw = flat - rb * ndw;                      // dword column inside the level image
-    const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
-    const size_t fbase = (size_t)frame * g.pyr_frame_bytes + L.plane_off;
-    // addresses = wave-uniform plane pointer + the lane's 32-bit offset (scalar base + vector offset
-    // in the load / store, one 32-bit add per row instead of 64-bit vector arithmetic)
-    const uint8_t* src = pyr + fbase;
-    uint8_t* dst = blur + fbase;
-    const uint32_t pitch = (uint32_t)L.pitch;
-    const uint32_t soff = __umul24((uint32_t)(kPadY + y0 - 3), pitch) + (uint32_t)(kPadX + 4 * dw - 4);
-    const uint32_t doff = __umul24((uint32_t)(kPadY + y0), pitch) + (uint32_t)(kPadX + 4 * dw);
-
-    // Branch-free schedule: 6 warm-up rows, then groups of 6 rows whose loads are all issued
-    // before the arithmetic.  A band's last group may run past the band (at most 5 rows): those
-    // rows are read from the stored border and written with the same values the next band
-    // writes (or into the unused border of the blurred plane).
-    // Column pass: the horizontal sums of rows t-1 and t are kept as one packed pair
-    // P[t % 6] = h(t-1) | h(t) << 16, so that output row n-6 (taps = rows n-6 .. n) is three
-    // 2-term dot products over the pairs of times n-5, n-3, n-1 plus the tap of row n.
     const ushort2_t W01 = {18, 34}, W23 = {49, 55}, W45 = {49, 34};
     uint32_t P[6][4], hprev[4];
 #pragma unroll
     for (int p = 0; p < 6; p++) {
-        uint32_t hc[4];
-        blur_hsum4(src + (size_t)(soff + __umul24((uint32_t)p, pitch)), hc);
+        uint32_t hc[4], a, b, c;
+        load3(0, p, a, b, c);
+        blur_hsum4w(a, b, c, hc);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             if (p > 0) P[p][j] = hprev[j] | (hc[j] << 16);
             hprev[j] = hc[j];
         }
     }
-    const int nrows = y1 - y0;
     for (int r0 = 0; r0 < nrows; r0 += 6) {
-        const uint32_t so = soff + __umul24((uint32_t)(r0 + 6), pitch), dofs = doff + __umul24((uint32_t)r0, pitch);   // rows, pitch < 2^24
+        const uint32_t dofs = doff + __umul24((uint32_t)r0, dpitch);   // rows, pitch < 2^24
         uint32_t raw[6][3];
 #pragma unroll
-        for (int p = 0; p < 6; p++) {
-            const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)(so + __umul24((uint32_t)p, pitch)));
-            raw[p][0] = q[0]; raw[p][1] = q[1]; raw[p][2] = q[2];
-        }
+        for (int p = 0; p < 6; p++) load3(r0 + 6, p, raw[p][0], raw[p][1], raw[p][2]);
 #pragma unroll
         for (int p = 0; p < 6; p++) {
             // row n = r0+6+p enters; r0 is a multiple of 6, so time n lives in slot p
@@ -370,17 +361,89 @@ __device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8
             // s >> 16 is at most 257: the high halves of two sums as a pair of 16-bit integers, saturated to two bytes
             const uint32_t lo = sat_pk_u8(__builtin_amdgcn_perm(acc[1], acc[0], 0x07060302u));
             const uint32_t hi = sat_pk_u8(__builtin_amdgcn_perm(acc[3], acc[2], 0x07060302u));
-            *reinterpret_cast<uint32_t*>(dst + (size_t)(dofs + __umul24((uint32_t)p, pitch))) = lo | (hi << 16);
+            *reinterpret_cast<uint32_t*>(dst + (size_t)(dofs + __umul24((uint32_t)p, dpitch))) = lo | (hi << 16);
         }
     }
 }
 
+// one work item (level, 64-dword column block, row band) on one wavefront; item and frame are wave-uniform
+__device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
+                                          const FrameGeom& g, const SlideMap& sm, int item, int lane, int frame,
+                                          const RawL0& raw)
+{
+    if (item >= sm.base[kMaxLevels]) return;
+    int level = 0;
+#pragma unroll
+    for (int l = 1; l < kMaxLevels; l++)
+        if (l < g.nlevels && item >= sm.base[l]) level = l;
+    const LevelGeom& L = g.lv[level];
+    // the level's (band, dword column) pairs are dealt to lanes in one flat sequence, so only the
+    // last wavefront of a level has idle lanes
+    const int flat = (item - sm.base[level]) * 64 + lane;
+    const int ndw = sm.ndw[level];
+    if (flat >= ndw * sm.nrb[level]) return;
+    const int rb = ndw == 1 ? flat : (int)__umulhi((uint32_t)flat, sm.rcp_ndw[level]);   // band
+    const int dw = flat - rb * ndw;                      // dword column inside the level image
+    const int y0 = min(rb * sm.rows[level], L.h - sm.rows[level]), y1 = y0 + sm.rows[level];
+    const size_t fbase = (size_t)frame * g.pyr_frame_bytes + L.plane_off;
+    // addresses = wave-uniform plane pointer + the lane's 32-bit offset (scalar base + vector offset
+    // in the load / store, one 32-bit add per row instead of 64-bit vector arithmetic)
+    uint8_t* dst = blur + fbase;
+    const uint32_t pitch = (uint32_t)L.pitch;
+    const uint32_t doff = __umul24((uint32_t)(kPadY + y0), pitch) + (uint32_t)(kPadX + 4 * dw);
+    const int nrows = y1 - y0;
+    if (raw.on && level == 0) {
+        // Level 0 from the caller's image (rows `stride` apart, no border around them): a buffer descriptor over the
+        // frame makes the few reads outside it (the dword left of column 0 in row 0, right of the last column in the
+        // last row) return zero instead of touching memory that is not the caller's.
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint8_t*>(raw.base + (size_t)frame * raw.frame_stride), 0, (int)raw.frame_bytes, 0x00020000);
+        typedef unsigned int v3u_t __attribute__((ext_vector_type(3)));
+        const uint32_t spitch = (uint32_t)raw.stride;
+        const int last_n = ((nrows + 5) / 6) * 6 + 5;                    // last source row counter a band loads
+        const bool edge = dw == 0 || dw == ndw - 1 || y0 < 3 || y0 - 3 + last_n > L.h - 1;
+        if (__ballot(edge) == 0ull) {                                     // wave-uniform: no lane needs a pixel outside the image
+            const uint32_t soff = __umul24((uint32_t)(y0 - 3), spitch) + (uint32_t)(4 * dw - 4);
+            blur_band([&](int nb, int p, uint32_t& a, uint32_t& b, uint32_t& c) {
+                const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(
+                    rsrc, (int)(soff + __umul24((uint32_t)nb, spitch) + __umul24((uint32_t)p, spitch)), 0, 0);
+                a = v.x; b = v.y; c = v.z;
+            }, dst, doff, pitch, nrows);
+        } else {
+            // REFLECT_101 formed here: rows by index (row -r is row r, row h - 1 + r is row h - 1 - r), the three pixels
+            // left of column 0 and right of column w - 1 by byte permutes of the dwords next to them
+            const bool left = dw == 0, right = dw == ndw - 1;
+            const int h2 = 2 * L.h - 2;
+            // an edge lane loads the 12 bytes that lie inside its row (columns 0 .. 11, or the last 12), so that no load
+            // leaves the frame, and moves them into place
+            const uint32_t coff = left ? 0u : (uint32_t)(right ? 4 * dw - 8 : 4 * dw - 4);
+            blur_band([&](int nb, int p, uint32_t& a, uint32_t& b, uint32_t& c) {
+                int r = y0 - 3 + nb + p;
+                r = max(r, -r);
+                r = min(r, h2 - r);
+                const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(__umul24((uint32_t)r, spitch) + coff), 0, 0);
+                const uint32_t cw = left ? v.x : (right ? v.z : v.y);
+                a = left ? __builtin_amdgcn_perm(v.y, v.x, 0x01020304u) : (right ? v.y : v.x);   // pixels -4 .. -1 = pixels 4, 3, 2, 1
+                b = cw;
+                c = right ? __builtin_amdgcn_perm(0u, cw, 0x00000102u) : (left ? v.y : v.z);     // pixels w .. w+2 = pixels w-2, w-3, w-4
+            }, dst, doff, pitch, nrows);
+        }
+        return;
+    }
+    const uint8_t* src = pyr + fbase;
+    const uint32_t soff = __umul24((uint32_t)(kPadY + y0 - 3), pitch) + (uint32_t)(kPadX + 4 * dw - 4);
+    blur_band([&](int nb, int p, uint32_t& a, uint32_t& b, uint32_t& c) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + (size_t)(soff + __umul24((uint32_t)nb, pitch) + __umul24((uint32_t)p, pitch)));
+        a = q[0]; b = q[1]; c = q[2];
+    }, dst, doff, pitch, nrows);
+}
+
 __global__ __launch_bounds__(256) void k_blur_slide(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur,
-                                                    FrameGeom g, SlideMap sm)
+                                                    FrameGeom g, SlideMap sm, RawL0 raw)
 {
     // wave-uniform: level, band and column block live in scalar registers
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    blur_item(pyr, blur, g, sm, item, threadIdx.x & 63, blockIdx.y);
+    blur_item(pyr, blur, g, sm, item, threadIdx.x & 63, blockIdx.y, raw);
 }
 
 // ---------------------------------------------------------------------------
@@ -545,7 +608,8 @@ __device__ unsigned long long g_fast_prof[16];
 template <int TPC, int SPC>
 __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, const FrameGeom& g, const FastLds& fl,
                                               uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
-                                              const FastCell* __restrict__ cells, int cell, int f, unsigned char* smem)
+                                              const FastCell* __restrict__ cells, int cell, int f, unsigned char* smem,
+                                              const RawL0& raw)
 {
     // one wavefront = one workgroup: wave-level fences replace workgroup barriers
     uint32_t* s_tile = reinterpret_cast<uint32_t*>(smem);
@@ -553,14 +617,18 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(smem + fl.queue_off);
     const int TP = TPC ? TPC : fl.tile_pitch, SP = SPC ? SPC : fl.score_pitch;
     const int lane = threadIdx.x;
-    const FastCell fc = cells[cell];                 // wave-uniform: one scalar load
+    // the cells of level 0 come first; with raw.on their tiles are cut out of the caller's image (a detection area
+    // stays 16 pixels inside the image, so a tile with its 3-pixel ring never touches the border)
+    const bool from_image = raw.on && cell < raw.ncells0;
+    const FastCell fc = from_image ? raw.cells0[cell] : cells[cell];   // wave-uniform: one scalar load
     const int cw = fc.cw, ch = fc.ch, ox = fc.ox, ndw = fc.ndw, pitch = fc.pitch, cell_cap = fc.cell_cap;
     int* count_out = cell_count + (size_t)f * g.ncells + cell;
     if (cw == 0) {
         if (lane == 0) *count_out = 0;
         return;
     }
-    const uint8_t* src = pyr + (size_t)f * g.pyr_frame_bytes + fc.src_off;
+    const uint8_t* src = (from_image ? raw.base + (size_t)f * raw.frame_stride : pyr + (size_t)f * g.pyr_frame_bytes) + fc.src_off;
+    const uint32_t src_left = (from_image ? raw.frame_bytes : g.pyr_frame_bytes) - fc.src_off;   // bytes from src to the end of the frame
     const int th = ch + 6;
     PROF_DECL;
     // Tile load: 16 lanes per tile row (32 when the pitch is not the compiled-in one), whole rows per
@@ -574,7 +642,7 @@ __device__ __forceinline__ void fast_one_cell(const uint8_t* __restrict__ pyr, c
         // tile, which is cleared right after.
         const int rr = lane >> 4, cc = lane & 15;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint8_t*>(src), 0, (int)(g.pyr_frame_bytes - (size_t)fc.src_off), 0x00020000);
+            const_cast<uint8_t*>(src), 0, (int)src_left, 0x00020000);
         if (cc < ndw) {
             const int so = __mul24(rr, pitch) + 4 * cc;
             uint32_t* d = s_tile + rr * (TPC >> 2) + cc;
@@ -941,7 +1009,7 @@ template <int TPC = 0, int SPC = 0>
 __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restrict__ pyr, FrameGeom g, FastLds fl,
                                                         uint32_t* __restrict__ cell_cand, int* __restrict__ cell_count,
                                                         const FastCell* __restrict__ cells, int frame_per_xcd,
-                                                        unsigned long long rcp_ncells, int nframes)
+                                                        unsigned long long rcp_ncells, int nframes, RawL0 raw)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2).  Neighbouring
@@ -960,7 +1028,7 @@ __global__ __launch_bounds__(64) void k_fast_cells_wave(const uint8_t* __restric
         cell = blockIdx.x;
         f = blockIdx.y;
     }
-    fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, cell, f, smem);
+    fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, cell, f, smem, raw);
 }
 
 // FAST and the blur in one launch: both only need the finished pyramid, so the blur's work items ride
@@ -972,7 +1040,8 @@ template <int TPC = 0, int SPC = 0>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fast_blur(const uint8_t* __restrict__ pyr, uint8_t* __restrict__ blur, FrameGeom g,
                                                   FastLds fl, SlideMap sm, uint32_t* __restrict__ cell_cand,
                                                   int* __restrict__ cell_count, const FastCell* __restrict__ cells,
-                                                  int frame_per_xcd, unsigned long long rcp_nitems, int nitems, int nframes)
+                                                  int frame_per_xcd, unsigned long long rcp_nitems, int nitems, int nframes,
+                                                  RawL0 raw)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     // large batches: every frame on one XCD, as in k_fast_cells_wave (nitems = cells + blur items per frame)
@@ -987,8 +1056,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         b = blockIdx.x;
         f = blockIdx.y;
     }
-    if (b < g.ncells) fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, b, f, smem);
-    else blur_item(pyr, blur, g, sm, b - g.ncells, threadIdx.x, f);
+    if (b < g.ncells) fast_one_cell<TPC, SPC>(pyr, g, fl, cell_cand, cell_count, cells, b, f, smem, raw);
+    else blur_item(pyr, blur, g, sm, b - g.ncells, threadIdx.x, f, raw);
 }
 
 #undef WAVE_SYNC
@@ -1836,7 +1905,7 @@ void make_fast_lds(const FrameGeom& g, FastLds& fl)
 }
 
 void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, const FastCell* cells,
-                            uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s)
+                            uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s, const RawL0& raw)
 {
     if (g.ncells == 0) return;
     static const int env_map = getenv("ORBX_FAST_XCD_MAP") ? atoi(getenv("ORBX_FAST_XCD_MAP")) : -1;
@@ -1846,10 +1915,10 @@ void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLd
     dim3 grid = per_xcd ? dim3((unsigned)(8 * g.ncells * ((nframes + 7) / 8))) : dim3(g.ncells, nframes);
     if (fl.fixed_pitch)
         hipLaunchKernelGGL((k_fast_cells_wave<kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr,
-                           g, fl, cell_cand, cell_count, cells, per_xcd, rcp, nframes);
+                           g, fl, cell_cand, cell_count, cells, per_xcd, rcp, nframes, raw);
     else
         hipLaunchKernelGGL(k_fast_cells_wave<>, grid, dim3(64), (size_t)fl.total, s, pyr, g, fl, cell_cand, cell_count,
-                           cells, per_xcd, rcp, nframes);
+                           cells, per_xcd, rcp, nframes, raw);
 }
 
 size_t quadtree_lds_bytes(int max_nodes) { return quadtree_fixed_lds(max_nodes); }
@@ -1931,7 +2000,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
                                                      const uint2* __restrict__ kp_stage,
                                                      const int* __restrict__ level_count,
                                                      orbx_keypoint* __restrict__ out_kps, uint8_t* __restrict__ out_desc,
-                                                     int cap, int* __restrict__ n_out, int nbx, int nframes, int frame_per_xcd)
+                                                     int cap, int* __restrict__ n_out, int nbx, int nframes, int frame_per_xcd,
+                                                     RawL0 raw)
 {
     // the 256 test pairs as floats, s_pat[j * 32 + byte] = (x0, y0, x1, y1) of pair 8 * byte + j
     __shared__ float4 s_pat[256];
@@ -2005,7 +2075,11 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
     // IC_Angle :74-101 on the un-blurred level: lane = patch column u = lane-15, walking the
     // rows |v| <= umax[|u|] of its column (the disc is symmetric in u and v); 31 independent,
     // row-coalesced byte loads per lane, m10 = u * (column sum).
-    const uint8_t* pf = pyr + (size_t)f * g.pyr_frame_bytes;
+    // (level 0 from the caller's image when raw.on: a keypoint lies at least 19 pixels inside, its patch 15)
+    const bool from_image = raw.on && level == 0;              // uniform over the workgroup
+    const uint8_t* pf = from_image ? raw.base + (size_t)f * raw.frame_stride : pyr + (size_t)f * g.pyr_frame_bytes;
+    const int mpitch = from_image ? raw.stride : pitch;
+    const int mctr = from_image ? y * raw.stride + x : ctr;
     int m10 = 0, m01 = 0;
     {
         const int u = lane - kHalfPatch;
@@ -2016,8 +2090,8 @@ __global__ __launch_bounds__(256) void k_orient_desc(FrameGeom g, const uint8_t*
             // unconditional load (rows +-15 of a keypoint always lie inside the plane) so that
             // all 31 loads are in flight together; rows outside the disc contribute zero
             const int av = v < 0 ? -v : v;
-            const int raw = pf[(uint32_t)(ctr + v * pitch + u)];
-            const int val = av <= d ? raw : 0;
+            const int px = pf[(uint32_t)(mctr + v * mpitch + u)];
+            const int val = av <= d ? px : 0;
             colsum += val;
             m01 += v * val;
         }
@@ -2105,7 +2179,7 @@ void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* 
 }
 
 void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
-                         int nframes, hipStream_t s)
+                         int nframes, hipStream_t s, const RawL0& raw)
 {
     const LevelGeom& L = g.lv[level];
     static const int env_rows = getenv("ORBX_RESIZE_ROWS") ? atoi(getenv("ORBX_RESIZE_ROWS")) : 0;
@@ -2119,7 +2193,7 @@ void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab
     const int nrows = mirror ? L.h : L.rows;
     const int nrb = (nrows + rows_per_band - 1) / rows_per_band;
     dim3 grid((ncb * nrb + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb, mirror);
+    hipLaunchKernelGGL(k_resize_slide, grid, dim3(256), 0, s, pyr, g, level, xtab, ytab, rows_per_band, ncb, mirror, raw);
 }
 
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
@@ -2145,7 +2219,8 @@ void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm)
 }
 
 void launch_fast_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const FastLds& fl, const SlideMap& sm,
-                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s)
+                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s,
+                      const RawL0& raw)
 {
     const int nitems = g.ncells + sm.base[kMaxLevels];
     static const int env_map = getenv("ORBX_FAST_XCD_MAP") ? atoi(getenv("ORBX_FAST_XCD_MAP")) : -1;
@@ -2154,17 +2229,17 @@ void launch_fast_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, con
     dim3 grid = per_xcd ? dim3((unsigned)(8 * nitems * ((nframes + 7) / 8))) : dim3(nitems, nframes);
     if (fl.fixed_pitch)
         hipLaunchKernelGGL((k_fast_blur<kFastTileFixed, kFastScoreFixed>), grid, dim3(64), (size_t)fl.total, s, pyr, blur, g,
-                           fl, sm, cell_cand, cell_count, cells, per_xcd, rcp, nitems, nframes);
+                           fl, sm, cell_cand, cell_count, cells, per_xcd, rcp, nitems, nframes, raw);
     else
         hipLaunchKernelGGL(k_fast_blur<>, grid, dim3(64), (size_t)fl.total, s, pyr, blur, g, fl, sm, cell_cand, cell_count,
-                           cells, per_xcd, rcp, nitems, nframes);
+                           cells, per_xcd, rcp, nitems, nframes, raw);
 }
 
 void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
-                       hipStream_t s)
+                       hipStream_t s, const RawL0& raw)
 {
     dim3 grid((sm.base[kMaxLevels] + 3) / 4, nframes);
-    hipLaunchKernelGGL(k_blur_slide, grid, dim3(256), 0, s, pyr, blur, g, sm);
+    hipLaunchKernelGGL(k_blur_slide, grid, dim3(256), 0, s, pyr, blur, g, sm, raw);
 }
 
 static int max_level_cells(const FrameGeom& g)
@@ -2282,13 +2357,13 @@ int quadtree_prepare(int max_nodes)
 
 void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
                         const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
-                        int nframes, hipStream_t s)
+                        int nframes, hipStream_t s, const RawL0& raw)
 {
     const int nbx = g.kp_per_frame > 0 ? (g.kp_per_frame + 7) / 8 : 1;
     const int per_xcd = nframes >= 32;                // one XCD per frame needs enough frames to keep all 8 busy
     dim3 grid = per_xcd ? dim3((unsigned)(8 * nbx * ((nframes + 7) / 8))) : dim3(nbx, nframes);
     hipLaunchKernelGGL(k_orient_desc, grid, dim3(256), 0, s, g, pyr, blur, reinterpret_cast<const uint2*>(kp_stage),
-                       level_count, out_kps, out_desc, cap, n_out, nbx, nframes, per_xcd);
+                       level_count, out_kps, out_desc, cap, n_out, nbx, nframes, per_xcd, raw);
 }
 
 } // namespace orbx

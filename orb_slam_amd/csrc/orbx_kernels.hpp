@@ -37,6 +37,21 @@ struct CountLevels {
 
 struct ScaleTab { float v[kMaxLevels]; };
 
+// Level 0 read from the caller's image instead of a copy of it in the pyramid block (resident batches whose rows are
+// dword-addressable): the FAST cells, the blur, the resize into level 1 and the orientation patches of level 0 take
+// their pixels from `base`; only the blur ever needs pixels outside the image (3 of them, REFLECT_101), and forms them
+// itself.  on == 0: every level is read from the pyramid block.
+struct RawL0 {
+    const uint8_t* base = nullptr;         // first frame
+    const FastCell* cells0 = nullptr;      // the level-0 entries of the FAST cell table, addressed into the image
+    const YTab2* ytab2_l1 = nullptr;       // the row table of level 1, addressed into the image
+    unsigned long long frame_stride = 0;   // bytes between frames
+    uint32_t frame_bytes = 0;              // h * stride: what a buffer descriptor of one frame covers
+    int stride = 0;                        // bytes per image row
+    int ncells0 = 0;                       // FAST cells of level 0 (the first cells of a frame)
+    int on = 0;
+};
+
 int upload_constant_tables(const int* gauss7, const int* umax16, hipStream_t s);
 
 void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8_t* pyr, const FrameGeom& g,
@@ -44,15 +59,16 @@ void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8
 void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,
                        int nframes, hipStream_t s);
 void launch_resize_slide(uint8_t* pyr, const FrameGeom& g, int level, const XTab4* xtab, const YTab2* ytab,
-                         int nframes, hipStream_t s);
+                         int nframes, hipStream_t s, const RawL0& raw = RawL0());
 void make_slide_map(const FrameGeom& g, int target_rows, SlideMap& sm);
 void launch_fast_blur(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const FastLds& fl, const SlideMap& sm,
-                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s);
+                      const FastCell* cells, uint32_t* cell_cand, int* cell_count, int nframes, hipStream_t s,
+                      const RawL0& raw = RawL0());
 void launch_blur_slide(const uint8_t* pyr, uint8_t* blur, const FrameGeom& g, const SlideMap& sm, int nframes,
-                       hipStream_t s);
+                       hipStream_t s, const RawL0& raw = RawL0());
 void make_fast_lds(const FrameGeom& g, FastLds& fl);
 void launch_fast_cells_wave(const uint8_t* pyr, const FrameGeom& g, const FastLds& fl, const FastCell* cells, uint32_t* cell_cand,
-                            int* cell_count, int nframes, hipStream_t s);
+                            int* cell_count, int nframes, hipStream_t s, const RawL0& raw = RawL0());
 size_t quadtree_lds_bytes(int max_nodes);
 int quadtree_prepare(int max_nodes);
 void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* cell_count, int* cell_off,
@@ -63,7 +79,7 @@ void quadtree_count_levels(const FrameGeom& g, CountLevels& cl);
 size_t quadtree_scratch_stride(const FrameGeom& g);
 void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* blur, const void* kp_stage,
                         const int* level_count, orbx_keypoint* out_kps, uint8_t* out_desc, int cap, int* n_out,
-                        int nframes, hipStream_t s);
+                        int nframes, hipStream_t s, const RawL0& raw = RawL0());
 
 // matching (orbx_match.hip)
 void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,

@@ -100,6 +100,57 @@ def test_large_batch_shapes(gpu, oracle, euroc_left):
         assert np.array_equal(res[i][1], desc_o)
 
 
+@pytest.mark.parametrize("w,h,nfeat,pad,gap", [(752, 480, 1000, 0, 0), (752, 480, 1000, 12, 4096), (640, 481, 800, 4, 8),
+                                                   (1024, 256, 1200, 0, 0), (316, 243, 500, 0, 0), (64, 64, 100, 8, 0),
+                                                   (2048, 1100, 3000, 0, 0)])
+def test_level0_read_from_the_image(w, h, nfeat, pad, gap, monkeypatch):
+    """Resident batches whose rows are dword-addressable read level 0 where it lies instead of copying it into the
+    pyramid block first (FAST cells, blur with its own REFLECT_101, resize into level 1, orientation patches); the
+    level-0 plane is made on demand.  Every stage against the oracle, with a row stride wider than the image and a gap
+    between frames, and the same call with the copy switched back on."""
+    import torch
+    from orb_slam_amd import ORBextractor
+    o = Oracle(nfeat, 1.2, 8, 20, 7)
+    ex = ORBextractor(nfeat, 1.2, 8, 20, 7)
+    dev = torch.device("cuda:0")
+    B = 3
+    imgs = synthetic_batch(B, w, h, seed0=6100 + w)
+    imgs[1] = np.random.default_rng(w).integers(0, 256, size=(h, w), dtype=np.uint8)      # noise: every edge pixel matters
+    stride, fstride = w + pad, (w + pad) * h + gap
+    buf = np.full(B * fstride + 64, 0xA5, np.uint8)
+    for b in range(B):
+        buf[b * fstride:b * fstride + stride * h].reshape(h, stride)[:, :w] = imgs[b]
+    cap = ex.max_keypoints(w, h)
+    results = {}
+    for mode in ("image", "copy", "image, unaligned base"):
+        if mode == "copy":
+            monkeypatch.setenv("ORBX_NO_RAW0", "1")
+        else:
+            monkeypatch.delenv("ORBX_NO_RAW0", raising=False)
+        shift = 1 if "unaligned" in mode else 0                  # an odd base address: the copy is taken by itself
+        d_buf = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), buf])).to(dev)
+        d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
+        d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)
+        d_n = torch.zeros((B,), dtype=torch.int32, device=dev)
+        ex.extract_batch_device(d_buf.data_ptr() + shift, B, w, h, stride, fstride, d_k, d_d, cap, d_n)
+        torch.cuda.synchronize()
+        n = d_n.cpu().numpy()
+        k = d_k.cpu().numpy().view(np.uint8).reshape(B, cap, 28)
+        d = d_d.cpu().numpy()
+        for b in range(B):
+            kps_o, desc_o = _compare_frame(ex, o, imgs[b], frame=b, check_stages=(mode != "copy" or b == 1))
+            assert n[b] == len(kps_o)
+            from orb_slam_amd import KP_DTYPE
+            kg = k[b, :n[b]].copy().view(KP_DTYPE).reshape(n[b])
+            assert np.array_equal(kg, kps_o) and np.array_equal(d[b, :n[b]], desc_o)
+        results[mode] = (n.copy(), k.copy(), d.copy())
+        del d_buf
+    for mode in ("copy", "image, unaligned base"):
+        for a, b_ in zip(results["image"], results[mode]):
+            assert np.array_equal(a, b_)
+    ex.close()
+
+
 def test_degenerate_frames(gpu, oracle):
     # constant image: no keypoints, descriptors released
     k, d = gpu(np.full((480, 752), 77, np.uint8))

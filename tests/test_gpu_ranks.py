@@ -30,3 +30,24 @@ def test_bench_spawns_its_ranks():
     assert d["result_gather"]["frames"] == 16 and d["result_gather"]["counts_and_payload_check"] == "ok"
     assert out["config"]["frames_per_step_whole_job"] == 16
     assert out["value"] > 0 and "invariant" in out
+
+
+def test_rccl_branch_executes_at_world_size_one():
+    """bench.py --force-dist initialises the nccl (= RCCL) process group on the one GPU of the box, so that the
+    RCCL initialisation, the timing barrier, the max-over-ranks all-reduce and the device-tensor result gather run
+    at least here before a multi-GPU node sees them."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--frames", "16", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-extras", "--settle-ms", "50"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    except (OSError, PermissionError) as e:
+        pytest.skip("could not start bench.py as a child process: %r" % (e,))
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    d = out["distributed"]
+    assert d["backend"].startswith("nccl") and d["world_size_initialised"] == 1
+    assert d["result_gather"]["frames"] == 16 and d["result_gather"]["counts_and_payload_check"] == "ok"
+    assert out["n_gpus"] == 1 and out["value"] > 0

@@ -1262,7 +1262,7 @@ static int stereo_launch(orbx_ctx* c, const orbx_keypoint* d_kl, const uint32_t*
     if (!(mb > 0.0f)) return fail(c, ORBX_ERR_INVALID, "baseline must be positive");
     if (th_orb_dist < 0 || th_orb_dist > 256) return fail(c, ORBX_ERR_INVALID, "th_orb_dist must be in [0, 256]");
     if (median_cut && !d_listed) return fail(c, ORBX_ERR_INVALID, "the median cut needs the listed-distance array");
-    if (nrows > 16000) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 16000 image rows");
+    if (nrows > kStereoMaxRows) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 16000 image rows");
     HIPCHECK(c, hipSetDevice(c->device));
     {   // scratch for the row ordering of the right keypoints
         const size_t need = stereo_rows_ints(nbatch, stride, nrows) * 4;
@@ -1426,7 +1426,7 @@ int orbx_stereo_match_sad_device(orbx_ctx* c, orbx_ctx* r, const orbx_keypoint* 
     if (c->gw != r->gw || c->gh != r->gh || c->p.nlevels != r->p.nlevels || c->p.scaleFactor != r->p.scaleFactor)
         return fail(c, ORBX_ERR_INVALID, "left and right contexts differ in frame size or pyramid parameters");
     if (nbatch > c->last_nframes || nbatch > r->last_nframes) return fail(c, ORBX_ERR_INVALID, "more pairs than frames in the pyramids");
-    if (c->g.lv[0].h > 32767) return fail(c, ORBX_ERR_UNSUPPORTED, "image taller than 32767 rows");
+    if (c->g.lv[0].h > kStereoMaxRows) return fail(c, ORBX_ERR_UNSUPPORTED, "image taller than 16000 rows");
     HIPCHECK(c, hipSetDevice(c->device));
     {   // the SAD windows read level-0 planes too
         int rc0 = materialise_level0(c);

@@ -110,6 +110,7 @@ struct StereoLaunch {
     int nbatch, stride, nrows, th_orb_dist, init_outputs, median_cut;
     float mbf, mb, min_x;
 };
+constexpr int kStereoMaxRows = 16000;   // image rows the row-band search accepts (two ints of LDS per row)
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s);
 size_t stereo_rows_ints(int nbatch, int stride, int nrows);
 size_t stereo_classic_ints(int nbatch, int stride, int nrows);

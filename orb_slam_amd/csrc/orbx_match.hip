@@ -915,8 +915,25 @@ size_t stereo_rows_ints(int nbatch, int stride, int nrows) { return (size_t)nbat
 // ints of scratch of the classic flow: the row ordering, then the three lists of the SAD refinement per pair
 size_t stereo_classic_ints(int nbatch, int stride, int nrows) { return stereo_rows_ints(nbatch, stride, nrows) + (size_t)nbatch * 3 * (size_t)stride; }
 
+// k_stereo_rows keeps two ints per image row in dynamic LDS: beyond 64 KB in all (rows above about 8000) the kernel
+// has to be told, once per process and device (the entry points accept up to kStereoMaxRows rows)
+static void stereo_rows_allow_lds(int nrows)
+{
+    if ((size_t)(2 * (nrows + 1)) * 4 + 1024 <= 64 * 1024) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static std::mutex mu;
+    static bool done[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev < 0 || dev >= 64 || done[dev]) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_stereo_rows), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (2 * (kStereoMaxRows + 1)) * 4);
+    done[dev] = true;
+}
+
 void launch_stereo_match(const StereoLaunch& L, const float* scale8, hipStream_t s)
 {
+    stereo_rows_allow_lds(L.nrows);
     ScaleTab sc;
     for (int i = 0; i < kMaxLevels; i++) sc.v[i] = scale8[i];
     StereoArgs a;
@@ -945,6 +962,7 @@ void launch_stereo_classic(const orbx_keypoint* d_kl, const uint32_t* d_dl, cons
     ScaleTab sc, isc;
     for (int i = 0; i < kMaxLevels; i++) { sc.v[i] = scale8[i]; isc.v[i] = inv_scale8[i]; }
     const int nrows = g.lv[0].h;
+    stereo_rows_allow_lds(nrows);
     StereoArgs a;
     a.kl = d_kl; a.kr = d_kr; a.dl = d_dl; a.dr = d_dr; a.nl = d_nl; a.nr = d_nr;
     a.active = nullptr; a.min_d = nullptr; a.max_d = nullptr; a.listed = nullptr;

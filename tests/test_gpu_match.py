@@ -276,6 +276,37 @@ def test_stereo_edge_cases(ex, matcher, oracle):
     assert (bi == -1).all() and (ur == -1).all() and nm == 0
 
 
+def test_stereo_on_very_tall_images(matcher, oracle):
+    """The row ordering keeps two integers per image row in LDS: 16000 rows (the accepted maximum) need 128 KB, beyond
+    what a launch gets without asking.  A few hundred keypoints spread over all rows against the oracle; one row more
+    is refused with an error code, not a launch failure."""
+    from orb_slam_amd import OrbxError
+    rng = np.random.default_rng(31)
+    sf = oracle.tables()["scale"]
+    for nrows in (9000, 16000):
+        n = 400
+        kl = np.zeros(n, KP_DTYPE)
+        kl["x"] = (rng.random(n) * 700 + 40).astype(np.float32)
+        kl["y"] = (rng.random(n) * (nrows - 1)).astype(np.float32)
+        kl["octave"] = rng.integers(0, 8, n)
+        kr = kl.copy()
+        kr["x"] -= (rng.random(n) * 30).astype(np.float32)
+        kr["y"] += rng.integers(-1, 2, n).astype(np.float32)
+        kr["y"] = np.clip(kr["y"], 0, nrows - 1)
+        dl = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        dr = dl.copy()
+        dr[:, :2] ^= rng.integers(0, 256, (n, 2), dtype=np.uint8)
+        mbf, mb = 47.9, 0.11
+        got = matcher.stereo_match(kl, dl, kr, dr, nrows, mbf, mb, 0.0)
+        f = oracle.stereo_frame(kl, dl, kr, dr, sf, nrows, mbf, mb, 0.0)
+        nm = f.ComputeStereoMatches_Undistorted(False)
+        assert got[4] == nm and nm > 100
+        assert np.array_equal(got[0], f.best_idx[:n]) and np.array_equal(got[1], f.best_dist[:n])
+        assert np.array_equal(got[2], f.mvuRight[:n]) and np.array_equal(got[3], f.mvDepth[:n])
+    with pytest.raises(OrbxError):
+        matcher.stereo_match(kl, dl, kr, dr, 16001, mbf, mb, 0.0)
+
+
 def test_stereo_classic_sad_refinement(ex, matcher):
     """Frame::ComputeStereoMatches with the SAD sub-pixel refinement on both extractors' pyramids."""
     from orb_slam_amd import ORBextractor

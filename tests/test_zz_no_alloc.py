@@ -68,3 +68,41 @@ def test_static_scratch_entry_point_matches_allocating_one():
         m.match_bruteforce_device_static(big_q, 64, 64, None, big_t, 1 << 22, 1 << 22, None, 1, *outs)
     assert ei.value.code == -5 and "2^22" in str(ei.value)
     ex.close()
+
+
+def test_static_scratch_entry_point_runs_under_stream_capture():
+    """What the entry point is for: it must be recordable into a HIP graph (a capture forbids hipMalloc / hipFree and
+    any synchronisation) at a shape never run before, and the replayed graph must give the allocating entry point's
+    results on new data.  (torch's capture context frees its own cached blocks, so the device's free memory is not
+    a usable witness here; the capture itself is: an allocation or a synchronisation inside it is an error.)"""
+    torch = pytest.importorskip("torch")
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex)
+    dev = torch.device("cuda", 0)
+    Q, T = 5000, 60000                       # several splits of the train set: the static scratch is in use
+    dq = torch.from_numpy(random_descriptors(Q, 21)).to(dev)
+    dt = torch.from_numpy(map_descriptors(T, random_descriptors(Q, 21), seed=22)).to(dev)
+    got = [torch.full((Q,), -9, dtype=torch.int32, device=dev) for _ in range(3)]
+    ref = [torch.full((Q,), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    side = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    ex.set_stream(side.cuda_stream)
+    with torch.cuda.graph(graph, stream=side):
+        m.match_bruteforce_device_static(dq, Q, Q, None, dt, T, T, None, 1, *got)
+    torch.cuda.synchronize()
+    assert int(got[0][0].item()) == -9                       # the capture only recorded
+    for rep in range(2):                                     # replay on changing data
+        if rep == 1:
+            dq.copy_(torch.from_numpy(random_descriptors(Q, 23)).to(dev))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        ex.set_stream(torch.cuda.current_stream().cuda_stream)
+        m.match_bruteforce_device(dq, Q, Q, None, dt, T, T, None, 1, *ref)
+        torch.cuda.synchronize()
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r)
+    ex.set_stream(None)
+    ex.close()

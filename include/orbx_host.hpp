@@ -272,6 +272,41 @@ struct DelayedStereo {
         return listed_dist[iL] >= 0;
     }
 
+    // Several one-point calls in one device call.  The reference calls the one-point form once per tracked map point
+    // (hundreds of times per frame); a whole-frame launch and a synchronisation per point would cost N times the work
+    // it needs.  A one-point call changes nothing another one reads, so the batch equals the calls made one after the
+    // other.  iL[k] with the window [minD[k], maxD[k]]; result[k] = what the k-th call returns.
+    std::vector<uint8_t> ComputeStereoMatch_Points(ORBextractor& ex, const std::vector<int>& iL, int thOrbDist,
+                                                   const std::vector<float>& minD, const std::vector<float>& maxD,
+                                                   const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc,
+                                                   const std::vector<orbx_keypoint>& keysRightUn, const uint8_t* descRight,
+                                                   int nRows, float mbf, float mb)
+    {
+        const int N = (int)keysUn.size();
+        std::vector<uint8_t> res(iL.size(), 0), active(N, 0);
+        if (minD.size() != iL.size() || maxD.size() != iL.size()) throw std::invalid_argument("one window per index");
+        std::vector<float> mn(N, 0.0f), mx(N, 0.0f);
+        std::vector<size_t> taken;
+        for (size_t k = 0; k < iL.size(); k++) {
+            const int i = iL[k];
+            if (i < 0 || i >= N || !has_mappoint[i] || mvStereoMatched[i]) continue;     // :1182-1186
+            mvStereoMatched[i] = 1;
+            active[i] = 1;
+            mn[i] = minD[k];
+            mx[i] = maxD[k];
+            taken.push_back(k);
+        }
+        if (taken.empty()) return res;
+        int nmatched = 0;
+        check(ex, orbx_stereo_match_ex(ex.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc), N,
+                                       keysRightUn.data(), reinterpret_cast<const uint32_t*>(descRight),
+                                       (int)keysRightUn.size(), nRows, mbf, mb, 0.0f, active.data(), mn.data(), mx.data(),
+                                       thOrbDist, 0, listed_dist.data(), best_idx.data(), best_dist.data(),
+                                       mvuRight.data(), mvDepth.data(), &nmatched));
+        for (size_t k : taken) res[k] = listed_dist[iL[k]] >= 0;
+        return res;
+    }
+
 private:
     static void check(ORBextractor& ex, int rc)
     {

@@ -140,3 +140,35 @@ class StereoFrame:
                                 self.nrows, self.mbf, self.mb, 0.0, active, min_d, max_d, int(thOrbDist), False,
                                 self.listed_dist, self.best_idx, self.best_dist, self.mvuRight, self.mvDepth)
         return bool(self.listed_dist[iL] >= 0)
+
+    def ComputeStereoMatch_Points(self, iLs, thOrbDist, minD, maxD):
+        """Several ComputeStereoMatch_OnePoint calls (src/Frame.cc:1175-1260) in one device call: the reference
+        calls the one-point form once per tracked map point, and a whole-frame launch per point costs N times the
+        work it needs.  iLs: left keypoint indices; minD / maxD: one disparity window per index (or scalars).  A
+        one-point call changes nothing another one reads, so the batch equals the calls made one after the other;
+        returns the array of their return values."""
+        iLs = np.asarray(iLs, np.int64).reshape(-1)
+        minD = np.broadcast_to(np.asarray(minD, np.float32), iLs.shape)
+        maxD = np.broadcast_to(np.asarray(maxD, np.float32), iLs.shape)
+        res = np.zeros(len(iLs), bool)
+        if self.N == 0 or len(iLs) == 0:
+            return res
+        active = np.zeros(self.N, np.uint8)
+        min_d = np.zeros(self.N, np.float32)
+        max_d = np.zeros(self.N, np.float32)
+        taken = []
+        for k, iL in enumerate(iLs):
+            if iL < 0 or iL >= self.N or not self.has_mappoint[iL] or self.mvStereoMatched[iL]:
+                continue                              # :1182-1186 (a second mention of one index finds it matched already)
+            self.mvStereoMatched[iL] = True
+            active[iL] = 1
+            min_d[iL], max_d[iL] = minD[k], maxD[k]
+            taken.append(k)
+        if taken:
+            self._m.stereo_match_ex(self.mvKeysUn, self.mDescriptors, self.mvKeysRightUn, self.mDescriptorsRight,
+                                    self.nrows, self.mbf, self.mb, 0.0, active, min_d, max_d, int(thOrbDist), False,
+                                    self.listed_dist, self.best_idx, self.best_dist, self.mvuRight, self.mvDepth)
+            for k in taken:
+                res[k] = self.listed_dist[iLs[k]] >= 0
+        return res
+

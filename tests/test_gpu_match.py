@@ -494,6 +494,17 @@ def test_stereo_delayed_matching(ex, matcher, oracle, n, seed, w, h):
         ro = o.ComputeStereoMatch_OnePoint(int(iL), th, mn, mx)
         assert rg == ro, iL
     _assert_stereo_state(g, o, "one point")
+    # more associations, matched by the batched form (one device call) against the oracle's one-point calls in order;
+    # the list holds an index twice, one without a map point and two outside the frame
+    more = np.flatnonzero((g.has_mappoint[:n] == 0) & ~g.mvStereoMatched[:n])[:40]
+    for f in (g, o):
+        f.has_mappoint[more[:-1]] = 1
+    idx = np.concatenate([more, more[:1], [-1, n]]).astype(np.int64)
+    mn_, mx_ = rng.uniform(0, 20, len(idx)).astype(np.float32), rng.uniform(30, 400, len(idx)).astype(np.float32)
+    rg = g.ComputeStereoMatch_Points(idx, 75, mn_, mx_)
+    ro = [o.ComputeStereoMatch_OnePoint(int(i), 75, float(a), float(b)) for i, a, b in zip(idx, mn_, mx_)]
+    assert rg.tolist() == ro
+    _assert_stereo_state(g, o, "several points")
     nm_g = g.ComputeStereoMatches_Undistorted(False)
     nm_o = o.ComputeStereoMatches_Undistorted(False)
     assert nm_g == nm_o

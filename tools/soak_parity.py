@@ -38,6 +38,8 @@ def main():
     frames = 0
     for case in range(n_cases):
         w, h = int(rng.integers(120, 1400)), int(rng.integers(100, 900))
+        if rng.random() < 0.6:
+            w &= ~3                      # rows that are dword-addressable: batches read level 0 from the image itself
         cfg = (int(rng.integers(50, 2500)), float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0])),
                int(rng.integers(1, 9)), int(rng.integers(8, 40)), int(rng.integers(2, 8)))
         try:
@@ -63,6 +65,19 @@ def main():
                 bad += 1
                 print("MISMATCH case %d rep %d %dx%d %s: %d vs %d keypoints" % (case, rep, w, h, cfg, len(kg), len(ko)))
                 np.save(os.path.join(ROOT, "gpurun_out", "soak_mismatch_%d_%d.npy" % (case, rep)), img)
+        else:
+            # the same geometry as a batch of five (uploaded in one piece, level 0 read in place where the rows allow it)
+            imgs = np.stack([make_image(rng, w, h) for _ in range(5)])
+            res = ex.extract_batch(imgs)
+            for i in range(5):
+                ko, do = orc.extract(imgs[i], literal=False)
+                kg, dg = res[i]
+                frames += 1
+                ok = len(kg) == len(ko) and (len(ko) == 0 or (all(np.array_equal(kg[f], ko[f]) for f in ko.dtype.names) and np.array_equal(dg, do)))
+                if not ok:
+                    bad += 1
+                    print("MISMATCH case %d batch frame %d %dx%d %s: %d vs %d keypoints" % (case, i, w, h, cfg, len(kg), len(ko)))
+                    np.save(os.path.join(ROOT, "gpurun_out", "soak_mismatch_%d_b%d.npy" % (case, i)), imgs[i])
         ex.close()
     print("soak: %d frames, %d mismatches" % (frames, bad))
     sys.exit(1 if bad else 0)

@@ -335,6 +335,23 @@ int orbx_search_by_projection(orbx_ctx *ctx, const orbx_keypoint *kps, const uin
                               const int32_t *mp_observations, int M, float th, float nnratio,
                               int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *nmatches);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono, numVisibleMpt),
+ * src/ORBmatcher.cc:1440-1593 -- the search of Tracking::TrackWithMotionModel -- from the point where the map points of
+ * the last frame have been projected into the current one (:1496 on).  The projection (:1451-1493) stays with the
+ * caller, who passes per keypoint i of the last frame: lp_visible (mvpMapPoints[i] exists, is no outlier, invzc >= 0,
+ * (u, v) inside the image bounds -- the points :1495 counts into numVisibleMpt), lp_u / lp_v / lp_invzc, lp_octave =
+ * LastFrame.mvKeys[i].octave, lp_angle = LastFrame.mvKeysUn[i].angle, lp_desc = the map point's descriptor,
+ * lp_observations = its Observations(); forward / backward as :1461-1462 decide them; mbf = CurrentFrame.mbf.
+ * Current frame as in orbx_search_by_projection.  frame_match[i2] = index i of the last frame's keypoint whose map
+ * point was assigned to CurrentFrame.mvpMapPoints[i2]; the rotation check (:1570-1590) resets what it removes to -1
+ * (frame_obs too: the reference stores NULL).  *nmatches = the return value. */
+int orbx_search_by_projection_last(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                   float min_x, float min_y, float inv_w, float inv_h,
+                                   const uint8_t *lp_visible, const float *lp_u, const float *lp_v, const float *lp_invzc,
+                                   const int32_t *lp_octave, const float *lp_angle, const uint32_t *lp_desc,
+                                   const int32_t *lp_observations, int M, float th, float mbf, int forward, int backward,
+                                   int check_orientation, int32_t *frame_obs, int32_t *frame_match, int *nmatches);
+
 /* --- keypoint undistortion --------------------------------------------------- */
 /* Frame::UndistortKeyPoints / UndistortKeyPointsStereo, src/Frame.cc:745-852: the keypoint
  * coordinates go through cv::undistortPoints(pts, K, dist, R, P) (fisheye = 0) or

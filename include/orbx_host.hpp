@@ -328,6 +328,16 @@ struct MapPointsInView {
     std::vector<uint8_t> descriptors;     // 32 bytes per map point (GetDescriptor())
 };
 
+// What ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) reads of each map point of
+// the last frame after projecting it (src/ORBmatcher.cc:1478-1510): visible = non-null, not an outlier, invzc >= 0
+// and (u, v) inside the image bounds; octave / angle = LastFrame.mvKeys[i]; parallel arrays of one length
+struct LastFramePoints {
+    std::vector<uint8_t> visible;
+    std::vector<float> u, v, invzc, angle;
+    std::vector<int32_t> octave, Observations;
+    std::vector<uint8_t> descriptors;     // 32 bytes per map point (GetDescriptor())
+};
+
 // The searches of ORB_SLAM2::ORBmatcher whose queries exclude what earlier queries claimed, with the
 // reference's constructor arguments (include/ORBmatcher.h: ORBmatcher(float nnratio = 0.6, bool checkOri = true)).
 // Candidate lists and distances come from the extractor's device; the sequential part runs inside the library.
@@ -378,6 +388,30 @@ public:
                                         reinterpret_cast<const uint32_t*>(mp.descriptors.data()), mp.Observations.data(),
                                         (int)M, th, mfNNratio, frame_obs.data(), frame_match.data(), mvpMatchScore.data(),
                                         &nmatches));
+        return nmatches;
+    }
+
+    // SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt), src/ORBmatcher.cc:1440-1593, from the
+    // projected points on: bForward / bBackward as computed at :1468-1469 (both false for a monocular frame), mbf =
+    // CurrentFrame.mbf, mvuRight = nullptr for a monocular frame.  frame_obs / frame_match as in the call above; the
+    // rotation check sets both to -1 for the matches it removes.  Returns nmatches.
+    int SearchByProjection(const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc, const std::vector<float>* mvuRight,
+                           const FrameGrid& grid, const LastFramePoints& last, float th, float mbf, bool bForward,
+                           bool bBackward, std::vector<int32_t>& frame_obs, std::vector<int32_t>& frame_match)
+    {
+        const size_t N = keysUn.size(), M = last.visible.size();
+        if (frame_obs.size() != N || frame_match.size() != N || last.u.size() != M || last.v.size() != M ||
+            last.invzc.size() != M || last.angle.size() != M || last.octave.size() != M || last.Observations.size() != M ||
+            last.descriptors.size() != 32 * M || (mvuRight && mvuRight->size() != N))
+            throw std::invalid_argument("array lengths do not agree");
+        int nmatches = 0;
+        check(orbx_search_by_projection_last(ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc),
+                                             mvuRight ? mvuRight->data() : nullptr, (int)N, grid.mnMinX, grid.mnMinY,
+                                             grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, last.visible.data(),
+                                             last.u.data(), last.v.data(), last.invzc.data(), last.octave.data(),
+                                             last.angle.data(), reinterpret_cast<const uint32_t*>(last.descriptors.data()),
+                                             last.Observations.data(), (int)M, th, mbf, bForward ? 1 : 0, bBackward ? 1 : 0,
+                                             mbCheckOrientation ? 1 : 0, frame_obs.data(), frame_match.data(), &nmatches));
         return nmatches;
     }
 

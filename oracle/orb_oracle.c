@@ -1901,3 +1901,79 @@ int oo_search_by_projection(const oo_keypoint *kps, const uint32_t *desc, const 
     free(qx); free(qy); free(qr); free(rr); free(qmin); free(qmax); free(off); free(idxs);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono,
+ * double &numVisibleMpt), src/ORBmatcher.cc:1440-1593, from the point where a map point of the last frame has been
+ * projected into the current one (:1496 on; the projection itself, :1451-1493, is the caller's geometry).
+ * lp_visible[i]: LastFrame.mvpMapPoints[i] exists, is no outlier, projects with invzc >= 0 inside the image bounds. */
+int oo_search_by_projection_last(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                 const float *scale_factors, float minX, float minY, float invW, float invH,
+                                 const uint8_t *lp_visible, const float *lp_u, const float *lp_v, const float *lp_invzc,
+                                 const int32_t *lp_octave, const float *lp_angle, const uint32_t *lp_desc,
+                                 const int32_t *lp_observations, int M, float th, float mbf, int bForward, int bBackward,
+                                 int check_orientation, int32_t *frame_obs, int32_t *frame_match)
+{
+    int nmatches = 0;
+    const size_t m1 = (size_t)(M > 0 ? M : 1);
+    int *rotHist[OO_HISTO_LENGTH], rotN[OO_HISTO_LENGTH];
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) { rotHist[i] = (int *)calloc(m1, sizeof(int)); rotN[i] = 0; }
+    const float factor = 1.0f / OO_HISTO_LENGTH;
+    float *qx = (float *)calloc(m1, sizeof(float)), *qy = (float *)calloc(m1, sizeof(float)), *qr = (float *)calloc(m1, sizeof(float));
+    int32_t *qmin = (int32_t *)calloc(m1, sizeof(int32_t)), *qmax = (int32_t *)calloc(m1, sizeof(int32_t));
+    int32_t *off = (int32_t *)calloc((size_t)M + 1, sizeof(int32_t));
+    for (int i = 0; i < M; i++) {
+        const int nLastOctave = lp_octave[i];
+        qx[i] = lp_u[i]; qy[i] = lp_v[i];
+        qr[i] = lp_visible[i] ? th * scale_factors[nLastOctave] : -1.0f;        /* :1499 */
+        if (bForward) { qmin[i] = nLastOctave; qmax[i] = -1; }                   /* :1503-1504 */
+        else if (bBackward) { qmin[i] = 0; qmax[i] = nLastOctave; }             /* :1505-1506 */
+        else { qmin[i] = nLastOctave - 1; qmax[i] = nLastOctave + 1; }          /* :1507-1508 */
+    }
+    const int total = oo_features_in_area(kps, N, minX, minY, invW, invH, qx, qy, qr, qmin, qmax, M, off, NULL, 0);
+    int32_t *idxs = (int32_t *)calloc((size_t)(total > 0 ? total : 1), sizeof(int32_t));
+    oo_features_in_area(kps, N, minX, minY, invW, invH, qx, qy, qr, qmin, qmax, M, off, idxs, total);
+    for (int i = 0; i < M; i++) {
+        if (!lp_visible[i]) continue;
+        const float u = lp_u[i], invzc = lp_invzc[i];
+        const float radius = qr[i];
+        if (off[i + 1] == off[i]) continue;                                    /* :1510-1511 */
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = off[i]; k < off[i + 1]; k++) {
+            const int i2 = idxs[k];
+            if (frame_obs[i2] > 0) continue;                                   /* :1521-1523 */
+            if (u_right && u_right[i2] > 0) {                                  /* :1525-1531 */
+                const float ur = u - mbf * invzc;
+                const float er = fabsf(ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int dist = oo_hamming(lp_desc + 8 * (size_t)i, desc + 8 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= OO_TH_HIGH) {                                          /* :1544 */
+            frame_match[bestIdx2] = i;
+            frame_obs[bestIdx2] = lp_observations[i];
+            nmatches++;
+            if (check_orientation) {                                           /* :1554-1564 */
+                float rot = lp_angle[i] - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == OO_HISTO_LENGTH) bin = 0;
+                rotHist[bin][rotN[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) {                                                   /* :1570-1590 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(rotN, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < rotN[i]; j++) {
+                    frame_match[rotHist[i][j]] = -1;                           /* mvpMapPoints[...] = NULL */
+                    frame_obs[rotHist[i][j]] = -1;
+                    nmatches--;
+                }
+    }
+    for (int i = 0; i < OO_HISTO_LENGTH; i++) free(rotHist[i]);
+    free(qx); free(qy); free(qr); free(qmin); free(qmax); free(off); free(idxs);
+    return nmatches;
+}

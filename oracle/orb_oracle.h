@@ -245,6 +245,20 @@ int oo_search_by_projection(const oo_keypoint *kps, const uint32_t *desc, const 
                             const int32_t *mp_observations, int M, float th, float nnratio,
                             int32_t *frame_obs, int32_t *frame_match, int32_t *match_score);
 
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono, numVisibleMpt),
+ * src/ORBmatcher.cc:1440-1593 (the search of TrackWithMotionModel), from :1496 on: the caller has projected the last
+ * frame's map points (u, v, invzc; lp_visible = the point exists, is no outlier and projects inside the image) and
+ * decided bForward / bBackward (:1461-1462).  lp_octave = LastFrame.mvKeys[i].octave, lp_angle =
+ * LastFrame.mvKeysUn[i].angle, lp_desc = the map point's descriptor, lp_observations = its Observations().
+ * Current frame as in oo_search_by_projection; a match removed by the rotation check resets frame_match and frame_obs
+ * to -1 (the reference stores NULL, :1585).  Returns nmatches. */
+int oo_search_by_projection_last(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                 const float *scale_factors, float minX, float minY, float invW, float invH,
+                                 const uint8_t *lp_visible, const float *lp_u, const float *lp_v, const float *lp_invzc,
+                                 const int32_t *lp_octave, const float *lp_angle, const uint32_t *lp_desc,
+                                 const int32_t *lp_observations, int M, float th, float mbf, int bForward, int bBackward,
+                                 int check_orientation, int32_t *frame_obs, int32_t *frame_match);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

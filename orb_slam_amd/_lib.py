@@ -69,6 +69,8 @@ SIGNATURES = {
     "orbx_search_for_initialization": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _i, _f, _i, _vp, _ip]),
     "orbx_search_by_projection": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _i, _f, _f, _vp, _vp, _vp, _ip]),
+    "orbx_search_by_projection_last": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                                            _f, _f, _i, _i, _i, _vp, _vp, _ip]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,
                                       _vp, _vp, _vp, _vp, _vp]),
     "orbx_stereo_match_ex": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _i, _i, _vp,

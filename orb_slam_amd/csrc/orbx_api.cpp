@@ -1864,6 +1864,100 @@ int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint3
     return ORBX_OK;
 }
 
+int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                                   float min_x, float min_y, float inv_w, float inv_h, const uint8_t* lp_visible,
+                                   const float* lp_u, const float* lp_v, const float* lp_invzc, const int32_t* lp_octave,
+                                   const float* lp_angle, const uint32_t* lp_desc, const int32_t* lp_observations, int M,
+                                   float th, float mbf, int forward, int backward, int check_orientation,
+                                   int32_t* frame_obs, int32_t* frame_match, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (M == 0 || N == 0) return ORBX_OK;
+    if (!kps || !desc || !lp_visible || !lp_u || !lp_v || !lp_octave || !lp_desc || !lp_observations || !frame_obs ||
+        !frame_match || (u_right && !lp_invzc) || (check_orientation && !lp_angle))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    constexpr int kThHigh = 100, kHisto = 30;          // TH_HIGH, HISTO_LENGTH (src/ORBmatcher.cc:38-39)
+    // the queries: the visible map points of the last frame, window th * mvScaleFactors[octave] (:1499), the level range
+    // by the direction of motion (:1503-1508)
+    std::vector<int32_t> qi;
+    qi.reserve(M);
+    for (int i = 0; i < M; i++) {
+        if (!lp_visible[i]) continue;
+        if (lp_octave[i] < 0 || lp_octave[i] >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "octave out of range");
+        qi.push_back(i);
+    }
+    const int Q = (int)qi.size();
+    if (Q == 0) return ORBX_OK;
+    std::vector<float> qx(Q), qy(Q), qr(Q);
+    std::vector<int32_t> qmin(Q), qmax(Q);
+    std::vector<uint32_t> qd((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) {
+        const int i = qi[q], o = lp_octave[i];
+        qx[q] = lp_u[i];
+        qy[q] = lp_v[i];
+        qr[q] = th * c->p.scale[o];
+        if (forward) { qmin[q] = o; qmax[q] = -1; }
+        else if (backward) { qmin[q] = 0; qmax[q] = o; }
+        else { qmin[q] = o - 1; qmax[q] = o + 1; }
+        std::memcpy(&qd[(size_t)q * 8], lp_desc + (size_t)i * 8, 32);
+    }
+    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
+    if (rc != ORBX_OK) return rc;
+    std::vector<int32_t> off, idx;
+    std::vector<uint16_t> dist;
+    rc = grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    if (rc != ORBX_OK) return rc;
+
+    int nm = 0;
+    std::vector<int32_t> rotHist[kHisto];
+    const float factor = 1.0f / kHisto;
+    for (int q = 0; q < Q; q++) {
+        const int i = qi[q];
+        if (off[q + 1] == off[q]) continue;                                   // :1510-1511
+        const float radius = qr[q];
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = off[q]; k < off[q + 1]; k++) {
+            const int i2 = idx[k];
+            if (frame_obs[i2] > 0) continue;                                  // :1521-1523
+            if (u_right && u_right[i2] > 0) {                                 // :1525-1531
+                const float ur = lp_u[i] - mbf * lp_invzc[i];
+                const float er = fabsf(ur - u_right[i2]);
+                if (er > radius) continue;
+            }
+            const int d = dist[k];
+            if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
+        }
+        if (bestDist <= kThHigh) {                                            // :1544
+            frame_match[bestIdx2] = i;
+            frame_obs[bestIdx2] = lp_observations[i];
+            nm++;
+            if (check_orientation) {                                          // :1554-1564
+                float rot = lp_angle[i] - kps[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == kHisto) bin = 0;
+                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
+                rotHist[bin].push_back(bestIdx2);
+            }
+        }
+    }
+    if (check_orientation) {                                                  // :1570-1590
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+        for (int b = 0; b < kHisto; b++)
+            if (b != ind1 && b != ind2 && b != ind3)
+                for (int i2 : rotHist[b]) {
+                    frame_match[i2] = -1;
+                    frame_obs[i2] = -1;
+                    nm--;
+                }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
 
 // K, dist, R, P -> the model the kernel evaluates; RR = P(:, 0:3) * R as cv::undistortPoints forms it
 static int undistort_model(orbx_ctx* c, const double* K, const double* dist, int ndist, const double* R, const double* P,

@@ -243,3 +243,28 @@ class ORBmatcher:
             vc.ctypes.data, md.ctypes.data, obs.ctypes.data, len(inview), float(th), self.mfNNratio,
             frame_obs.ctypes.data, frame_match.ctypes.data, match_score.ctypes.data, C.byref(nm)))
         return nm.value
+
+    def SearchByProjectionLast(self, keys, desc, mvuRight, grid, last, th, mbf, bForward, bBackward, frame_obs, frame_match):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) (src/ORBmatcher.cc:1440-1593)
+        from :1496 on.  last: dict of per-keypoint arrays of the last frame (visible, u, v, invzc, octave, angle,
+        descriptor, Observations); frame_obs / frame_match: int32 arrays over the current keypoints, updated in
+        place.  Returns nmatches."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        d = _desc(desc)
+        ur = None if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        for a in (frame_obs, frame_match):
+            if a.dtype != np.int32 or not a.flags.c_contiguous or len(a) < len(kps):
+                raise ValueError("frame arrays must be contiguous int32 arrays of N entries")
+        vis = np.ascontiguousarray(last["visible"], np.uint8)
+        u, v, iz, ang = (np.ascontiguousarray(last[k], np.float32) for k in ("u", "v", "invzc", "angle"))
+        octv = np.ascontiguousarray(last["octave"], np.int32)
+        obs = np.ascontiguousarray(last["Observations"], np.int32)
+        ld = _desc(last["descriptor"])
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_projection_last(
+            self._ctx, kps.ctypes.data, d.ctypes.data, ptr(ur), len(kps), grid[0], grid[1], grid[2], grid[3],
+            vis.ctypes.data, u.ctypes.data, v.ctypes.data, iz.ctypes.data, octv.ctypes.data, ang.ctypes.data,
+            ld.ctypes.data, obs.ctypes.data, len(vis), float(th), float(mbf), int(bool(bForward)), int(bool(bBackward)),
+            int(bool(self.mbCheckOrientation)), frame_obs.ctypes.data, frame_match.ctypes.data, C.byref(nm)))
+        return nm.value
+

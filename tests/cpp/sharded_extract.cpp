@@ -3,7 +3,8 @@
 // orbx::ORBmatcher::SearchForInitialization between the first two frames, dumped for the caller to compare.
 //   sharded_extract <raw_u8_file> <w> <h> <nframes> <devices, e.g. 0,0,0> <out_file>
 // raw file: nframes frames back to back.  Prints "sharded ok: ..." when sharded == single for every frame.
-// out_file: int32 n1, nmatches; n1 x int32 vnMatches12; n1 x 2 float vbPrevMatched
+// out_file: int32 n1, nmatches; n1 x int32 vnMatches12; n1 x 2 float vbPrevMatched; then the last-frame projection
+// search of frame 0's keypoints in frame 1: int32 n2, nmatches; n2 x int32 frame_match; n2 x int32 frame_obs
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -71,8 +72,25 @@ int main(int argc, char** argv)
             std::fwrite(hdr, 4, 2, o);
             std::fwrite(m12.data(), 4, m12.size(), o);
             std::fwrite(prev.data(), 4, prev.size(), o);
+            // frame-to-frame search (src/Tracking.cc:2204): the first frame's keypoints as the last frame's map points,
+            // projected where they were seen, monocular (no right coordinate, no forward / backward), th = 15
+            orbx::LastFramePoints last;
+            last.visible.assign(a.size(), 1);
+            last.invzc.assign(a.size(), 1.0f);
+            last.Observations.assign(a.size(), 1);
+            for (const orbx_keypoint& k : a) {
+                last.u.push_back(k.x); last.v.push_back(k.y); last.angle.push_back(k.angle); last.octave.push_back(k.octave);
+            }
+            last.descriptors.assign(d2.begin(), d2.begin() + 32 * a.size());
+            std::vector<int32_t> fobs(b.size(), -1), fmatch(b.size(), -1);
+            const int nm2 = matcher.SearchByProjection(b, d2.data() + (size_t)cap * 32, nullptr, grid, last, 15.0f, 0.0f, false,
+                                                       false, fobs, fmatch);
+            int32_t hdr2[2] = {(int32_t)b.size(), nm2};
+            std::fwrite(hdr2, 4, 2, o);
+            std::fwrite(fmatch.data(), 4, fmatch.size(), o);
+            std::fwrite(fobs.data(), 4, fobs.size(), o);
             std::fclose(o);
-            std::printf("SearchForInitialization: %d matches\n", nm);
+            std::printf("SearchForInitialization: %d matches, SearchByProjection(last frame): %d\n", nm, nm2);
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "%s\n", e.what());

@@ -106,6 +106,9 @@ class Oracle:
         lib.oo_search_by_projection.argtypes = [C.c_void_p, _u32p, _f32p, C.c_int, _f32p, C.c_float, C.c_float,
                                                 C.c_float, C.c_float, _u8p, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p,
                                                 _u32p, _i32p, C.c_int, C.c_float, C.c_float, _i32p, _i32p, _i32p]
+        lib.oo_search_by_projection_last.argtypes = [C.c_void_p, _u32p, _f32p, C.c_int, _f32p, C.c_float, C.c_float, C.c_float,
+                                                     C.c_float, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _u32p, _i32p,
+                                                     C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -385,6 +388,27 @@ class Oracle:
             _ptr(py, _f32p), _ptr(pxr, _f32p), _ptr(lvl, _i32p), _ptr(vc, _f32p), _ptr(md.view(np.uint32), _u32p),
             _ptr(obs, _i32p), len(inview), th, nnratio, _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
             _ptr(match_score, _i32p))
+
+    def search_by_projection_last(self, kps, desc, u_right, grid, last, th, mbf, forward, backward, check_ori,
+                                  frame_obs, frame_match):
+        """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, ...) from :1496 on; frame arrays updated in place"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sf = self.tables()["scale"]
+        vis = np.ascontiguousarray(last["visible"], np.uint8)
+        u, v, iz, ang = (np.ascontiguousarray(last[k], np.float32) for k in ("u", "v", "invzc", "angle"))
+        octv = np.ascontiguousarray(last["octave"], np.int32)
+        obs = np.ascontiguousarray(last["Observations"], np.int32)
+        ld = np.ascontiguousarray(last["descriptor"], np.uint8).reshape(-1, 32)
+        for a in (frame_obs, frame_match):
+            assert a.dtype == np.int32 and a.flags.c_contiguous and len(a) >= len(kps)
+        return self.lib.oo_search_by_projection_last(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), len(kps),
+            _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3], _ptr(vis, _u8p), _ptr(u, _f32p), _ptr(v, _f32p),
+            _ptr(iz, _f32p), _ptr(octv, _i32p), _ptr(ang, _f32p), _ptr(ld.view(np.uint32), _u32p), _ptr(obs, _i32p),
+            len(vis), th, mbf, int(bool(forward)), int(bool(backward)), int(bool(check_ori)), _ptr(frame_obs, _i32p),
+            _ptr(frame_match, _i32p))
 
     def undistort_points(self, xy, K, dist=None, R=None, P=None, fisheye=False):
         xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)

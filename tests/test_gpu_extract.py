@@ -432,8 +432,8 @@ def test_cpp_host_program(oracle, euroc_left, tmp_path):
 def test_cpp_sharded_extractor_and_matcher(oracle, euroc_left, euroc_right, tmp_path):
     """orbx::ShardedExtractor (one context + host thread per listed device, contiguous frame ranges, results in the
     caller's arrays in frame order) equals a single context on every frame -- three shards on the one GPU of the
-    test box, 7 frames, so the shards get 2, 2 and 3 -- and orbx::ORBmatcher::SearchForInitialization on the first
-    two frames equals the oracle's."""
+    test box, 7 frames, so the shards get 2, 2 and 3 -- and orbx::ORBmatcher::SearchForInitialization and the
+    last-frame SearchByProjection on the first two frames equal the oracle's."""
     import os
     import subprocess
     from orb_slam_amd.synth import synthetic_batch
@@ -459,6 +459,17 @@ def test_cpp_sharded_extractor_and_matcher(oracle, euroc_left, euroc_right, tmp_
     assert n1 == len(k1) and nm == nm_o and nm > 20
     assert np.array_equal(np.frombuffer(buf, np.int32, n1, 8), m_o)
     assert np.array_equal(np.frombuffer(buf, np.float32, 2 * n1, 8 + 4 * n1).reshape(n1, 2), prev)
+    # orbx::ORBmatcher::SearchByProjection(current, last frame): frame 0's keypoints searched in frame 1
+    off = 8 + 12 * n1
+    n2, nm2 = np.frombuffer(buf, np.int32, 2, off)
+    last = {"visible": np.ones(len(k1), np.uint8), "u": k1["x"].copy(), "v": k1["y"].copy(),
+            "invzc": np.ones(len(k1), np.float32), "octave": k1["octave"].astype(np.int32),
+            "angle": k1["angle"].astype(np.float32), "Observations": np.ones(len(k1), np.int32), "descriptor": d1}
+    fo, fm = np.full(len(k2), -1, np.int32), np.full(len(k2), -1, np.int32)
+    nm_o2 = oracle.search_by_projection_last(k2, d2, None, grid, last, 15.0, 0.0, False, False, True, fo, fm)
+    assert n2 == len(k2) and nm2 == nm_o2 and nm2 > 20
+    assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8), fm)
+    assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8 + 4 * n2), fo)
 
 
 def test_cpp_adapter_program(euroc_left, tmp_path):

@@ -184,3 +184,74 @@ def test_projection_search_with_collisions(matcher, oracle, seed, stereo, th):
     assert _both_projection(matcher, oracle, kps, desc, u_right, e, th, 0.8, obs0)[0] == 0
     none_in_view = dict(mp, mbTrackInView=np.zeros(len(mp["isBad"]), np.uint8))
     assert _both_projection(matcher, oracle, kps, desc, u_right, none_in_view, th, 0.8, obs0)[0] == 0
+
+
+# ---- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt), src/ORBmatcher.cc:1440-1593 ----
+def _both_projection_last(matcher, oracle, kps, desc, u_right, last, th, mbf, fwd, bwd, ori, obs0):
+    from orb_slam_amd import ORBmatcher
+    m = ORBmatcher(matcher._ex, nnratio=0.9, checkOri=ori)
+    res = []
+    for side in (m, oracle):
+        fo, fm = obs0.copy(), np.full(len(kps), -1, np.int32)
+        if side is oracle:
+            nm = oracle.search_by_projection_last(kps, desc, u_right, GRID, last, th, mbf, fwd, bwd, ori, fo, fm)
+        else:
+            nm = m.SearchByProjectionLast(kps, desc, u_right, GRID, last, th, mbf, fwd, bwd, fo, fm)
+        res.append((nm, fo, fm))
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    return res[0]
+
+
+def test_last_frame_projection_search_on_the_euroc_pair(oracle, euroc_left, euroc_right):
+    """Tracking::TrackWithMotionModel (src/Tracking.cc:2196-2216): th = 15 (mono) or 7 (stereo), the search repeated
+    with 2*th when fewer than 20 matches come back.  The last frame = the right image, its map points projected
+    where the row-band stereo search found them in the left image (jittered)."""
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex, nnratio=0.9, checkOri=True)
+    kl, dl = ex(euroc_left)
+    kr, dr = ex(euroc_right)
+    bi, bd, ur, dp, _ = m.stereo_match(kl, dl, kr, dr, 480, 47.9, 0.11, 0.0)
+    rng = np.random.default_rng(78)
+    has = np.nonzero(bi >= 0)[0]
+    M = len(has)
+    last = {
+        "visible": (rng.random(M) < 0.95).astype(np.uint8),
+        "u": (kl["x"][has] + rng.normal(0, 2.0, M)).astype(np.float32),
+        "v": (kl["y"][has] + rng.normal(0, 2.0, M)).astype(np.float32),
+        "invzc": (dp[has] / np.float32(47.9)).astype(np.float32) if (dp[has] > 0).all() else rng.uniform(0.05, 1, M).astype(np.float32),
+        "octave": kr["octave"][bi[has]].astype(np.int32),
+        "angle": kr["angle"][bi[has]].astype(np.float32),
+        "Observations": rng.choice([0, 2, 5], M).astype(np.int32),
+        "descriptor": dr[bi[has]],
+    }
+    obs0 = np.where(rng.random(len(kl)) < 0.05, 3, -1).astype(np.int32)
+    for th, u_right in ((15.0, None), (7.0, ur), (14.0, ur)):
+        for fwd, bwd in ((False, False), (True, False), (False, True)):
+            for ori in (True, False):
+                nm, fo, fm = _both_projection_last(m, oracle, kl, dl, u_right, last, th, 47.9, fwd, bwd, ori, obs0)
+                assert nm > 80
+    ex.close()
+
+
+@pytest.mark.parametrize("seed,stereo,fwd,bwd,th", [(31, False, False, False, 15.0), (32, True, True, False, 7.0),
+                                                   (33, True, False, True, 7.0), (34, True, False, False, 30.0)])
+def test_last_frame_projection_search_with_collisions(matcher, oracle, seed, stereo, fwd, bwd, th):
+    from test_oracle_search import _last_frame_points
+    rng = np.random.default_rng(seed)
+    kps, desc, _, _ = _random_frames(rng, 3000, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    last = _last_frame_points(rng, kps, desc, 2500)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.random(len(kps)).astype(np.float32) * 40, -1).astype(np.float32)
+    obs0 = rng.choice([-1, -1, -1, 0, 2], len(kps)).astype(np.int32)
+    for ori in (True, False):
+        nm, fo, fm = _both_projection_last(matcher, oracle, kps, desc, u_right, last, th, 40.0, fwd, bwd, ori, obs0)
+        assert nm > 300
+    e = {k: v[:0] for k, v in last.items()}
+    assert _both_projection_last(matcher, oracle, kps, desc, u_right, e, th, 40.0, fwd, bwd, True, obs0)[0] == 0
+    hidden = dict(last, visible=np.zeros(len(last["u"]), np.uint8))
+    assert _both_projection_last(matcher, oracle, kps, desc, u_right, hidden, th, 40.0, fwd, bwd, True, obs0)[0] == 0
+    assert _both_projection_last(matcher, oracle, kps[:0], desc[:0], None, last, th, 40.0, fwd, bwd, True, obs0[:0])[0] == 0

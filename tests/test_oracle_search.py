@@ -383,3 +383,140 @@ def test_projection_search_rules(oracle):
     assert run([5], [1], view_cos=0.999)[0] == 0             # |97.5 - 101| = 3.5 >= 2.5 * 1.2 = 3.0
     assert run([5], [1], view_cos=0.9)[0] == 1               # 3.5 < 4.8
     assert run([5], [1], view_cos=0.999, th=1.5)[0] == 1     # 3.5 < 4.5
+
+
+# ---- ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt), src/ORBmatcher.cc:1440-1593 ----
+def _last_frame_points(rng, kps, desc, M):
+    """map points of the last frame projected near keypoints of the current one"""
+    pick = rng.integers(0, len(kps), M)
+    last = {
+        "visible": (rng.random(M) < 0.9).astype(np.uint8),
+        "u": (kps["x"][pick] + rng.normal(0, 2.0, M)).astype(np.float32),
+        "v": (kps["y"][pick] + rng.normal(0, 2.0, M)).astype(np.float32),
+        "invzc": rng.uniform(0.02, 1.0, M).astype(np.float32),
+        "octave": np.clip(kps["octave"][pick] + rng.integers(-1, 2, M), 0, 7).astype(np.int32),
+        "angle": ((kps["angle"][pick] + rng.choice([0.0, 0.0, 0.0, 1.5, 60.0, 200.0], M)) % 360).astype(np.float32),
+        "Observations": rng.choice([0, 1, 4], M).astype(np.int32),
+    }
+    bits = np.unpackbits(desc[pick], axis=1)
+    last["descriptor"] = np.packbits(bits ^ (rng.random(bits.shape) < 0.05), axis=1)
+    return last
+
+
+def _py_search_by_projection_last(kps, desc, u_right, grid, last, th, mbf, fwd, bwd, check_ori, sf, frame_obs, frame_match):
+    nm = 0
+    hist = [[] for _ in range(30)]
+    for i in range(len(last["visible"])):
+        if not last["visible"][i]:
+            continue
+        o = int(last["octave"][i])
+        radius = np.float32(np.float32(th) * sf[o])
+        lv = (o, -1) if fwd else ((0, o) if bwd else (o - 1, o + 1))
+        cands = _py_features_in_area(kps, grid, last["u"][i], last["v"][i], radius, lv[0], lv[1])
+        best, bi = 256, -1
+        for i2 in cands:
+            if frame_obs[i2] > 0:
+                continue
+            if u_right is not None and u_right[i2] > 0:
+                ur = np.float32(last["u"][i] - np.float32(np.float32(mbf) * last["invzc"][i]))
+                if abs(np.float32(ur - u_right[i2])) > radius:
+                    continue
+            d = _ham(last["descriptor"][i], desc[i2])
+            if d < best:
+                best, bi = d, i2
+        if best <= 100:
+            frame_match[bi] = i
+            frame_obs[bi] = last["Observations"][i]
+            nm += 1
+            if check_ori:
+                rot = np.float32(last["angle"][i]) - np.float32(kps["angle"][bi])
+                if rot < 0:
+                    rot = np.float32(rot + np.float32(360))
+                b = int(np.floor(float(np.float32(rot * np.float32(1.0 / 30))) + 0.5))
+                hist[0 if b == 30 else b].append(bi)
+    if check_ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: (-sizes[i], i))[:3]
+        keep = [order[0]] if sizes[order[0]] > 0 else []
+        for o_ in order[1:]:
+            if sizes[o_] > 0 and not (np.float32(sizes[o_]) < np.float32(0.1) * np.float32(sizes[order[0]])):
+                keep.append(o_)
+            else:
+                break
+        for b in range(30):
+            if b not in keep:
+                for bi in hist[b]:
+                    frame_match[bi] = -1
+                    frame_obs[bi] = -1
+                    nm -= 1
+    return nm
+
+
+@pytest.mark.parametrize("seed,stereo,fwd,bwd,th", [(1, False, False, False, 15.0), (2, True, True, False, 7.0),
+                                                   (3, True, False, True, 7.0), (4, True, False, False, 14.0)])
+def test_last_frame_projection_search_against_python_statement(oracle, seed, stereo, fwd, bwd, th):
+    rng = np.random.default_rng(200 + seed)
+    kps, desc, _, _ = _random_frames(rng, 500, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    sf = oracle.tables()["scale"]
+    last = _last_frame_points(rng, kps, desc, 350)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.random(len(kps)).astype(np.float32) * 40, -1).astype(np.float32)
+    obs0 = rng.choice([-1, -1, -1, 0, 3], len(kps)).astype(np.int32)
+    for ori in (True, False):
+        outs = []
+        for side in ("oracle", "python"):
+            fo, fm = obs0.copy(), np.full(len(kps), -1, np.int32)
+            if side == "oracle":
+                nm = oracle.search_by_projection_last(kps, desc, u_right, GRID, last, th, 40.0, fwd, bwd, ori, fo, fm)
+            else:
+                nm = _py_search_by_projection_last(kps, desc, u_right, GRID, last, th, 40.0, fwd, bwd, ori, sf, fo, fm)
+            outs.append((nm, fo, fm))
+        assert outs[0][0] == outs[1][0] and outs[0][0] > 30
+        assert np.array_equal(outs[0][1], outs[1][1]) and np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_last_frame_projection_search_rules(oracle):
+    kps = _kps([(100, 100), (103, 100), (400, 300)], octave=[2, 3, 2], angle=[10.0, 10.0, 10.0])
+    desc = _desc_with_bits([0, 30, 0])
+
+    def run(bits, obs, octave=2, fwd=False, bwd=False, frame_obs=(-1, -1, -1), u_right=None, invzc=0.5, th=3.0, angle=10.0, ori=False):
+        M = len(bits)
+        last = {"visible": np.ones(M, np.uint8), "u": np.full(M, 101, np.float32), "v": np.full(M, 100, np.float32),
+                "invzc": np.full(M, invzc, np.float32), "octave": np.full(M, octave, np.int32),
+                "angle": np.full(M, angle, np.float32), "Observations": np.array(obs, np.int32),
+                "descriptor": _desc_with_bits(bits)}
+        fo, fm = np.array(frame_obs, np.int32), np.full(3, -1, np.int32)
+        nm = oracle.search_by_projection_last(kps, desc, u_right, GRID, last, th, 40.0, fwd, bwd, ori, fo, fm)
+        return nm, fo.tolist(), fm.tolist()
+
+    # radius = th * scale[2] = 3 * 1.44 = 4.32: both near keypoints are candidates (levels 1..3); the best one wins, no ratio test
+    assert run([12], [2]) == (1, [2, -1, -1], [0, -1, -1])
+    assert run([20], [2]) == (1, [-1, 2, -1], [-1, 0, -1])            # 20 vs 10 -> keypoint 1
+    assert run([15], [2])[2] == [0, -1, -1]                             # equal distances: the first candidate stays (strict <)
+    # forward motion: levels >= the last octave; backward: levels <= it
+    assert run([20], [2], octave=3, fwd=True)[2] == [-1, 0, -1]
+    assert run([1], [2], octave=3, fwd=True)[2] == [-1, 0, -1]         # keypoint 0 (level 2) is not seen at all
+    assert run([29], [2], octave=2, bwd=True)[2] == [0, -1, -1]        # keypoint 1 (level 3) is not seen
+    # a second point cannot take a keypoint whose map point has observations, but does overwrite one without
+    assert run([12, 11], [2, 2]) == (2, [2, 2, -1], [0, 1, -1])
+    assert run([12, 11], [0, 2]) == (2, [2, -1, -1], [1, -1, -1])
+    # TH_HIGH
+    kps["x"][1] = 300
+    assert run([100], [1])[0] == 1 and run([101], [1])[0] == 0
+    kps["x"][1] = 103
+    # right-image gate: ur = u - mbf * invzc = 101 - 20 = 81; |81 - uR| > radius 4.32 -> skipped
+    ur = np.array([86.0, -1.0, -1.0], np.float32)
+    assert run([12], [1], u_right=ur)[2] == [-1, 0, -1]
+    ur[0] = 85.0
+    assert run([12], [1], u_right=ur)[2] == [0, -1, -1]
+    # rotation check: two matches in bin 0 and one in bin 4 (rot 120): 1 >= 0.1 * 2 keeps it; with 11 in bin 0 it goes
+    kq = _kps([(50 + 30 * i, 60) for i in range(12)], octave=2, angle=0.0)
+    dq = np.random.default_rng(1).integers(0, 256, (12, 32), dtype=np.uint8)
+    last = {"visible": np.ones(12, np.uint8), "u": kq["x"].copy(), "v": kq["y"].copy(), "invzc": np.full(12, 0.5, np.float32),
+            "octave": np.full(12, 2, np.int32), "angle": np.array([0.0] * 11 + [120.0], np.float32),
+            "Observations": np.full(12, 1, np.int32), "descriptor": dq}
+    fo, fm = np.full(12, -1, np.int32), np.full(12, -1, np.int32)
+    assert oracle.search_by_projection_last(kq, dq, None, GRID, last, 3.0, 40.0, False, False, True, fo, fm) == 11
+    assert fm.tolist() == list(range(11)) + [-1] and fo.tolist() == [1] * 11 + [-1]

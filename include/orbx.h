@@ -335,6 +335,45 @@ int orbx_search_by_projection(orbx_ctx *ctx, const orbx_keypoint *kps, const uin
                               const int32_t *mp_observations, int M, float th, float nnratio,
                               int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *nmatches);
 
+/* ORBmatcher::SearchByProjection_Budget(F, vpMapPoints, th, time_constr), src/ORBmatcher.cc:45-153 (the search of
+ * Tracking::SearchAdditionalMatchesInFrame, src/Tracking.cc:2240): orbx_search_by_projection under a wall clock, started
+ * when the call is entered and read after every map point that was accepted or whose best distance is above TH_HIGH
+ * (:140-146; the reference's `continue`s skip the clock, so do these); the loop ends once time_constr_ms have passed.
+ * *stopped_at = the map point after which it ended, M when it ran to the end.  The clock makes the result depend on
+ * the machine, in the reference as here; with a budget that is never reached the result is orbx_search_by_projection's,
+ * with 0 the loop ends after the first map point that reaches the clock. */
+int orbx_search_by_projection_budget(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, const float *u_right,
+                                     int N, float min_x, float min_y, float inv_w, float inv_h,
+                                     const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                                     const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                                     const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                                     const int32_t *mp_observations, int M, float th, float nnratio, double time_constr_ms,
+                                     int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *nmatches,
+                                     int *stopped_at);
+/* ORBmatcher::GetCandidates(F, pMP, th), include/ORBmatcher.h:151-171, for all M map points in one device call, with
+ * the descriptor distance of every candidate: cand_off[M + 1], cand_idx / cand_dist[cap] = pMP->mvMatchCandidates of
+ * every point (GetFeaturesInArea order; empty for a point that is not in view or bad) and DescriptorDistance(
+ * pMP->GetDescriptor(), F.mDescriptors.row(idx)) beside each index.  *total = cand_off[M]; with cap < *total (or NULL
+ * buffers) the offsets are filled and ORBX_ERR_CAPACITY comes back.  Src/Observability.cc:1309-1329 runs this loop
+ * before it draws map points one at a time. */
+int orbx_projection_candidates(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, int N,
+                               float min_x, float min_y, float inv_w, float inv_h,
+                               const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                               const float *mp_proj_x, const float *mp_proj_y, const int32_t *mp_level,
+                               const float *mp_view_cos, const uint32_t *mp_desc, int M, float th,
+                               int32_t *cand_off, int32_t *cand_idx, uint16_t *cand_dist, int cap, int *total);
+/* ORBmatcher::MatchCandidates(F, pMP, th), include/ORBmatcher.h:173-252, and -- on the list orbx_projection_candidates
+ * made for the point -- ORBmatcher::SearchByProjection_OnePoint(F, pMP, th), :68-149 (src/Observability.cc:1413, :1685):
+ * one map point against its candidate list and the frame's current assignment.  Host arithmetic only (the distances
+ * are in the list), so the caller can interleave it with its own work in any order; frame_obs / frame_match /
+ * match_score as in orbx_search_by_projection, mp_index = what frame_match receives.  *best_idx = the return value
+ * (-1: no match). */
+int orbx_match_candidates(orbx_ctx *ctx, const orbx_keypoint *kps, const float *u_right, int N,
+                          const int32_t *cand_idx, const uint16_t *cand_dist, int ncand,
+                          int track_in_view, int is_bad, float proj_xr, int level, float view_cos, float th, float nnratio,
+                          int mp_index, int mp_observations,
+                          int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *best_idx);
+
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono, numVisibleMpt),
  * src/ORBmatcher.cc:1440-1593 -- the search of Tracking::TrackWithMotionModel -- from the point where the map points of
  * the last frame have been projected into the current one (:1496 on).  The projection (:1451-1493) stays with the

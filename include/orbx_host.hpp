@@ -328,6 +328,14 @@ struct MapPointsInView {
     std::vector<uint8_t> descriptors;     // 32 bytes per map point (GetDescriptor())
 };
 
+// pMP->mvMatchCandidates of every map point (include/MapPoint.h, filled by ORBmatcher::GetCandidates) with the
+// descriptor distance of every candidate: the list of map point i is [cand_off[i], cand_off[i + 1])
+struct MatchCandidateTable {
+    std::vector<int32_t> cand_off, cand_idx;
+    std::vector<uint16_t> cand_dist;
+    size_t size(size_t i) const { return (size_t)(cand_off[i + 1] - cand_off[i]); }
+};
+
 // What ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) reads of each map point of
 // the last frame after projecting it (src/ORBmatcher.cc:1478-1510): visible = non-null, not an outlier, invzc >= 0
 // and (u, v) inside the image bounds; octave / angle = LastFrame.mvKeys[i]; parallel arrays of one length
@@ -373,11 +381,7 @@ public:
                            std::vector<int32_t>& frame_match, std::vector<int32_t>& mvpMatchScore)
     {
         const size_t N = keysUn.size(), M = mp.mbTrackInView.size();
-        if (frame_obs.size() != N || frame_match.size() != N || mvpMatchScore.size() != N ||
-            mp.mTrackProjX.size() != M || mp.mTrackProjY.size() != M || mp.mnTrackScaleLevel.size() != M ||
-            mp.mTrackViewCos.size() != M || mp.Observations.size() != M || mp.descriptors.size() != 32 * M ||
-            (mvuRight && (mvuRight->size() != N || mp.mTrackProjXR.size() != M)) || (!mp.isBad.empty() && mp.isBad.size() != M))
-            throw std::invalid_argument("array lengths do not agree");
+        check_lengths(N, M, mp, mvuRight, frame_obs, frame_match, mvpMatchScore);
         int nmatches = 0;
         check(orbx_search_by_projection(ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc),
                                         mvuRight ? mvuRight->data() : nullptr, (int)N, grid.mnMinX, grid.mnMinY,
@@ -389,6 +393,86 @@ public:
                                         (int)M, th, mfNNratio, frame_obs.data(), frame_match.data(), mvpMatchScore.data(),
                                         &nmatches));
         return nmatches;
+    }
+
+    // SearchByProjection_Budget(F, vpMapPoints, th, time_constr), src/ORBmatcher.cc:45-153: the call above under a wall
+    // clock (milliseconds since the call was entered).  stopped_at = the map point after which the loop ended, or M.
+    int SearchByProjection_Budget(const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc, const std::vector<float>* mvuRight,
+                                  const FrameGrid& grid, const MapPointsInView& mp, float th, double time_constr,
+                                  std::vector<int32_t>& frame_obs, std::vector<int32_t>& frame_match,
+                                  std::vector<int32_t>& mvpMatchScore, int* stopped_at = nullptr)
+    {
+        const size_t N = keysUn.size(), M = mp.mbTrackInView.size();
+        check_lengths(N, M, mp, mvuRight, frame_obs, frame_match, mvpMatchScore);
+        int nmatches = 0, stop = 0;
+        check(orbx_search_by_projection_budget(ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc),
+                                               mvuRight ? mvuRight->data() : nullptr, (int)N, grid.mnMinX, grid.mnMinY,
+                                               grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, mp.mbTrackInView.data(),
+                                               mp.isBad.empty() ? nullptr : mp.isBad.data(), mp.mTrackProjX.data(),
+                                               mp.mTrackProjY.data(), mp.mTrackProjXR.empty() ? nullptr : mp.mTrackProjXR.data(),
+                                               mp.mnTrackScaleLevel.data(), mp.mTrackViewCos.data(),
+                                               reinterpret_cast<const uint32_t*>(mp.descriptors.data()), mp.Observations.data(),
+                                               (int)M, th, mfNNratio, time_constr, frame_obs.data(), frame_match.data(),
+                                               mvpMatchScore.data(), &nmatches, &stop));
+        if (stopped_at) *stopped_at = stop;
+        return nmatches;
+    }
+
+    // GetCandidates(F, pMP, th), include/ORBmatcher.h:151-171, for every map point at once (the loop of
+    // src/Observability.cc:1309-1329), the distances of all candidates included
+    MatchCandidateTable GetCandidates(const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc, const FrameGrid& grid,
+                                      const MapPointsInView& mp, float th)
+    {
+        const size_t N = keysUn.size(), M = mp.mbTrackInView.size();
+        if (mp.mTrackProjX.size() != M || mp.mTrackProjY.size() != M || mp.mnTrackScaleLevel.size() != M ||
+            mp.mTrackViewCos.size() != M || mp.descriptors.size() != 32 * M || (!mp.isBad.empty() && mp.isBad.size() != M))
+            throw std::invalid_argument("array lengths do not agree");
+        MatchCandidateTable t;
+        t.cand_off.assign(M + 1, 0);
+        int total = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            const int rc = orbx_projection_candidates(
+                ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc), (int)N, grid.mnMinX, grid.mnMinY,
+                grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, mp.mbTrackInView.data(),
+                mp.isBad.empty() ? nullptr : mp.isBad.data(), mp.mTrackProjX.data(), mp.mTrackProjY.data(),
+                mp.mnTrackScaleLevel.data(), mp.mTrackViewCos.data(), reinterpret_cast<const uint32_t*>(mp.descriptors.data()),
+                (int)M, th, t.cand_off.data(), t.cand_idx.data(), t.cand_dist.data(), (int)t.cand_idx.size(), &total);
+            if (rc == ORBX_ERR_CAPACITY && pass == 0) {       // the first pass asked for the size
+                t.cand_idx.resize(total);
+                t.cand_dist.resize(total);
+                continue;
+            }
+            check(rc);
+            break;
+        }
+        return t;
+    }
+
+    // MatchCandidates(F, pMP, th), include/ORBmatcher.h:173-252, = SearchByProjection_OnePoint(F, pMP, th), :68-149, on the
+    // table GetCandidates made: map point i against the frame's assignment as it stands.  Returns bestIdx or -1.
+    int MatchCandidates(const std::vector<orbx_keypoint>& keysUn, const std::vector<float>* mvuRight,
+                        const MatchCandidateTable& t, const MapPointsInView& mp, size_t i, float th,
+                        std::vector<int32_t>& frame_obs, std::vector<int32_t>& frame_match, std::vector<int32_t>& mvpMatchScore)
+    {
+        const size_t N = keysUn.size();
+        if (i + 1 >= t.cand_off.size() || frame_obs.size() != N || frame_match.size() != N || mvpMatchScore.size() != N ||
+            (mvuRight && mvuRight->size() != N))
+            throw std::invalid_argument("array lengths do not agree");
+        int best = -1;
+        const int a = t.cand_off[i];
+        check(orbx_match_candidates(ex_.context(), keysUn.data(), mvuRight ? mvuRight->data() : nullptr, (int)N,
+                                    t.cand_idx.data() + a, t.cand_dist.data() + a, (int)t.size(i), mp.mbTrackInView[i],
+                                    mp.isBad.empty() ? 0 : mp.isBad[i], mp.mTrackProjXR.empty() ? 0.0f : mp.mTrackProjXR[i],
+                                    mp.mnTrackScaleLevel[i], mp.mTrackViewCos[i], th, mfNNratio, (int)i, mp.Observations[i],
+                                    frame_obs.data(), frame_match.data(), mvpMatchScore.data(), &best));
+        return best;
+    }
+    int SearchByProjection_OnePoint(const std::vector<orbx_keypoint>& keysUn, const std::vector<float>* mvuRight,
+                                    const MatchCandidateTable& t, const MapPointsInView& mp, size_t i, float th,
+                                    std::vector<int32_t>& frame_obs, std::vector<int32_t>& frame_match,
+                                    std::vector<int32_t>& mvpMatchScore)
+    {
+        return MatchCandidates(keysUn, mvuRight, t, mp, i, th, frame_obs, frame_match, mvpMatchScore);
     }
 
     // SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt), src/ORBmatcher.cc:1440-1593, from the
@@ -419,6 +503,16 @@ private:
     void check(int rc)
     {
         if (rc != ORBX_OK) throw std::runtime_error(std::string("liborbx: ") + orbx_last_error(ex_.context()));
+    }
+    static void check_lengths(size_t N, size_t M, const MapPointsInView& mp, const std::vector<float>* mvuRight,
+                              const std::vector<int32_t>& frame_obs, const std::vector<int32_t>& frame_match,
+                              const std::vector<int32_t>& mvpMatchScore)
+    {
+        if (frame_obs.size() != N || frame_match.size() != N || mvpMatchScore.size() != N ||
+            mp.mTrackProjX.size() != M || mp.mTrackProjY.size() != M || mp.mnTrackScaleLevel.size() != M ||
+            mp.mTrackViewCos.size() != M || mp.Observations.size() != M || mp.descriptors.size() != 32 * M ||
+            (mvuRight && (mvuRight->size() != N || mp.mTrackProjXR.size() != M)) || (!mp.isBad.empty() && mp.isBad.size() != M))
+            throw std::invalid_argument("array lengths do not agree");
     }
     ORBextractor& ex_;
 

@@ -8,12 +8,14 @@
  * evaluated as written (one IEEE-754 rounding per operation), which is also
  * what the GPU kernels do.
  */
+#define _POSIX_C_SOURCE 199309L   /* clock_gettime for the budgeted search */
 #include "orb_oracle.h"
 
 #include <math.h>
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------------- */
 /* OpenCV 3.4.1 semantics: scalar helpers                                     */
@@ -1975,5 +1977,154 @@ int oo_search_by_projection_last(const oo_keypoint *kps, const uint32_t *desc, c
     }
     for (int i = 0; i < OO_HISTO_LENGTH; i++) free(rotHist[i]);
     free(qx); free(qy); free(qr); free(qmin); free(qmax); free(off); free(idxs);
+    return nmatches;
+}
+
+/* ------------------------------------------------------------------------- *
+ * The good-feature forms of the projection search: one map point per call
+ * (ORBmatcher::SearchByProjection_OnePoint, include/ORBmatcher.h:68-149;
+ * GetCandidates :151-171 + MatchCandidates :173-252, which split the same body
+ * in two) and the loop with a time budget (SearchByProjection_Budget,
+ * src/ORBmatcher.cc:45-153).  Frame state as in oo_search_by_projection:
+ * frame_obs[i] = Observations() of F.mvpMapPoints[i] or -1, frame_match[i] =
+ * the map point written into F.mvpMapPoints[i], match_score = F.mvpMatchScore.
+ * ------------------------------------------------------------------------- */
+/* GetCandidates, include/ORBmatcher.h:151-171: returns the list length (0 when the point is skipped) */
+int oo_get_candidates(const oo_keypoint *kps, int N, const float *scale_factors, float minX, float minY,
+                      float invW, float invH, int track_in_view, int is_bad, float proj_x, float proj_y,
+                      int level, float view_cos, float th, int32_t *cand_idx, int cap)
+{
+    const int bFactor = th != 1.0;                                         /* :153 */
+    if (!track_in_view) return 0;                                          /* :155-156 */
+    if (is_bad) return 0;                                                  /* :158-159 */
+    float r = radius_by_viewing_cos(view_cos);                             /* :164 */
+    if (bFactor) r *= th;                                                  /* :166-167 */
+    const float qr = r * scale_factors[level];
+    const int32_t qmin = level - 1, qmax = level;                          /* :169-170 */
+    int32_t off[2];
+    return oo_features_in_area(kps, N, minX, minY, invW, invH, &proj_x, &proj_y, &qr, &qmin, &qmax, 1, off, cand_idx, cap);
+}
+
+/* MatchCandidates, include/ORBmatcher.h:173-252, on the list GetCandidates stored in the map point */
+int oo_match_candidates(const oo_keypoint *kps, const uint32_t *desc, const float *u_right,
+                        const float *scale_factors, const int32_t *cand_idx, int ncand,
+                        int track_in_view, int is_bad, float proj_xr, int level, float view_cos,
+                        const uint32_t *mp_desc, int mp_observations, int mp_index, float th, float nnratio,
+                        int32_t *frame_obs, int32_t *frame_match, int32_t *match_score)
+{
+    if (!track_in_view) return -1;                                         /* :176-177 */
+    if (is_bad) return -1;                                                 /* :179-180 */
+    if (ncand == 0) return -1;                                             /* :182-183 */
+    float r = radius_by_viewing_cos(view_cos);                             /* :188 */
+    const int bFactor = th != 1.0;
+    if (bFactor) r *= th;                                                  /* :190-192 */
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < ncand; k++) {                                      /* :203-235 */
+        const int idx = cand_idx[k];
+        if (frame_obs[idx] > 0) continue;
+        if (u_right && u_right[idx] > 0) {
+            const float er = fabsf(proj_xr - u_right[idx]);
+            if (er > r * scale_factors[level]) continue;
+        }
+        const int dist = oo_hamming(mp_desc, desc + 8 * (size_t)idx);
+        if (dist < bestDist) {
+            bestDist2 = bestDist; bestDist = dist;
+            bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx;
+        } else if (dist < bestDist2) {
+            bestLevel2 = kps[idx].octave; bestDist2 = dist;
+        }
+    }
+    if (bestDist <= OO_TH_HIGH) {                                          /* :238-249 */
+        if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) return -1;
+        frame_match[bestIdx] = mp_index;
+        frame_obs[bestIdx] = mp_observations;
+        match_score[bestIdx] = bestDist;
+        return bestIdx;
+    }
+    return -1;
+}
+
+/* SearchByProjection_OnePoint, include/ORBmatcher.h:68-149: the two halves above in one call */
+int oo_search_by_projection_one_point(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                      const float *scale_factors, float minX, float minY, float invW, float invH,
+                                      int track_in_view, int is_bad, float proj_x, float proj_y, float proj_xr,
+                                      int level, float view_cos, const uint32_t *mp_desc, int mp_observations,
+                                      int mp_index, float th, float nnratio,
+                                      int32_t *frame_obs, int32_t *frame_match, int32_t *match_score)
+{
+    if (!track_in_view || is_bad) return -1;                               /* :72-76 */
+    int32_t *list = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    const int n = oo_get_candidates(kps, N, scale_factors, minX, minY, invW, invH, 1, 0, proj_x, proj_y, level,
+                                    view_cos, th, list, N);                /* :86-90 */
+    const int best = oo_match_candidates(kps, desc, u_right, scale_factors, list, n, 1, 0, proj_xr, level, view_cos,
+                                         mp_desc, mp_observations, mp_index, th, nnratio, frame_obs, frame_match,
+                                         match_score);                     /* :92-148 */
+    free(list);
+    return best;
+}
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+
+/* SearchByProjection_Budget, src/ORBmatcher.cc:45-153: the loop of oo_search_by_projection with a wall clock read
+ * after every map point that reaches the end of the loop body (:140-146; the `continue`s before it skip the clock).
+ * The clock makes the result depend on the machine; it is deterministic at the two ends: a budget never reached
+ * (the result of SearchByProjection) and a budget of 0 (the loop ends after the first map point that reaches :140).
+ * *stopped_at = index of the map point after which the loop broke, M when it ran to the end. */
+int oo_search_by_projection_budget(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                   const float *scale_factors, float minX, float minY, float invW, float invH,
+                                   const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                                   const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                                   const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                                   const int32_t *mp_observations, int M, float th, float nnratio, double time_constr,
+                                   int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *stopped_at)
+{
+    int nmatches = 0;
+    const int bFactor = th != 1.0;                                         /* :51 */
+    const double t0 = now_ms();                                            /* :54-55 */
+    int32_t *list = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    *stopped_at = M;
+    for (int iMP = 0; iMP < M; iMP++) {
+        if (!mp_track_in_view[iMP]) continue;                              /* :60-61 */
+        if (mp_is_bad[iMP]) continue;                                      /* :63-64 */
+        const int nPredictedLevel = mp_level[iMP];
+        float r = radius_by_viewing_cos(mp_view_cos[iMP]);                 /* :69 */
+        if (bFactor) r *= th;                                              /* :71-72 */
+        const float qr = r * scale_factors[nPredictedLevel];
+        const int32_t qmin = nPredictedLevel - 1, qmax = nPredictedLevel;
+        int32_t off[2];
+        const int n = oo_features_in_area(kps, N, minX, minY, invW, invH, &mp_proj_x[iMP], &mp_proj_y[iMP], &qr, &qmin,
+                                          &qmax, 1, off, list, N);         /* :74-75 */
+        if (n == 0) continue;                                              /* :77-78 */
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int k = 0; k < n; k++) {                                      /* :89-121 */
+            const int idx = list[k];
+            if (frame_obs[idx] > 0) continue;
+            if (u_right && u_right[idx] > 0) {
+                const float er = fabsf(mp_proj_xr[iMP] - u_right[idx]);
+                if (er > r * scale_factors[nPredictedLevel]) continue;
+            }
+            const int dist = oo_hamming(mp_desc + 8 * (size_t)iMP, desc + 8 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist;
+                bestLevel2 = bestLevel; bestLevel = kps[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = kps[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= OO_TH_HIGH) {                                      /* :124-138 */
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            frame_match[bestIdx] = iMP;
+            frame_obs[bestIdx] = mp_observations[iMP];
+            match_score[bestIdx] = bestDist;
+            nmatches++;
+        }
+        if (now_ms() - t0 >= time_constr) { *stopped_at = iMP; break; }    /* :141-146 */
+    }
+    free(list);
     return nmatches;
 }

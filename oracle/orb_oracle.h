@@ -259,6 +259,35 @@ int oo_search_by_projection_last(const oo_keypoint *kps, const uint32_t *desc, c
                                  const int32_t *lp_observations, int M, float th, float mbf, int bForward, int bBackward,
                                  int check_orientation, int32_t *frame_obs, int32_t *frame_match);
 
+/* The good-feature forms of the projection search (one map point per call, or a loop under a time budget); frame
+ * state as in oo_search_by_projection.
+ * oo_get_candidates: ORBmatcher::GetCandidates, include/ORBmatcher.h:151-171 -> list length, indices in cand_idx.
+ * oo_match_candidates: ORBmatcher::MatchCandidates, :173-252 -> bestIdx or -1.
+ * oo_search_by_projection_one_point: ORBmatcher::SearchByProjection_OnePoint, :68-149 -> bestIdx or -1.
+ * oo_search_by_projection_budget: ORBmatcher::SearchByProjection_Budget, src/ORBmatcher.cc:45-153; time_constr in
+ * ms; *stopped_at = the map point after which the budget ended the loop, M when it ran to the end. */
+int oo_get_candidates(const oo_keypoint *kps, int N, const float *scale_factors, float minX, float minY,
+                      float invW, float invH, int track_in_view, int is_bad, float proj_x, float proj_y,
+                      int level, float view_cos, float th, int32_t *cand_idx, int cap);
+int oo_match_candidates(const oo_keypoint *kps, const uint32_t *desc, const float *u_right,
+                        const float *scale_factors, const int32_t *cand_idx, int ncand,
+                        int track_in_view, int is_bad, float proj_xr, int level, float view_cos,
+                        const uint32_t *mp_desc, int mp_observations, int mp_index, float th, float nnratio,
+                        int32_t *frame_obs, int32_t *frame_match, int32_t *match_score);
+int oo_search_by_projection_one_point(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                      const float *scale_factors, float minX, float minY, float invW, float invH,
+                                      int track_in_view, int is_bad, float proj_x, float proj_y, float proj_xr,
+                                      int level, float view_cos, const uint32_t *mp_desc, int mp_observations,
+                                      int mp_index, float th, float nnratio,
+                                      int32_t *frame_obs, int32_t *frame_match, int32_t *match_score);
+int oo_search_by_projection_budget(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                                   const float *scale_factors, float minX, float minY, float invW, float invH,
+                                   const uint8_t *mp_track_in_view, const uint8_t *mp_is_bad,
+                                   const float *mp_proj_x, const float *mp_proj_y, const float *mp_proj_xr,
+                                   const int32_t *mp_level, const float *mp_view_cos, const uint32_t *mp_desc,
+                                   const int32_t *mp_observations, int M, float th, float nnratio, double time_constr,
+                                   int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *stopped_at);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -1785,25 +1786,18 @@ int orbx_search_for_initialization(orbx_ctx* c, const orbx_keypoint* k1, const u
     return ORBX_OK;
 }
 
-int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
-                              float min_x, float min_y, float inv_w, float inv_h, const uint8_t* mp_track_in_view,
-                              const uint8_t* mp_is_bad, const float* mp_proj_x, const float* mp_proj_y,
-                              const float* mp_proj_xr, const int32_t* mp_level, const float* mp_view_cos,
-                              const uint32_t* mp_desc, const int32_t* mp_observations, int M, float th, float nnratio,
-                              int32_t* frame_obs, int32_t* frame_match, int32_t* match_score, int* nmatches)
+// The queries of a projection search over map points (src/ORBmatcher.cc:161-179 = :57-75 = include/ORBmatcher.h:151-170):
+// the points in view that are not bad, window r * mvScaleFactors[level] on levels [level - 1, level]; then every
+// candidate list of the call with its distances.  qi = map point of each query, rr = its r.
+static int projection_queries(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y,
+                              float inv_w, float inv_h, const uint8_t* mp_track_in_view, const uint8_t* mp_is_bad,
+                              const float* mp_proj_x, const float* mp_proj_y, const int32_t* mp_level,
+                              const float* mp_view_cos, const uint32_t* mp_desc, int M, float th, std::vector<int32_t>& qi,
+                              std::vector<float>& rr, std::vector<int32_t>& off, std::vector<int32_t>& idx,
+                              std::vector<uint16_t>& dist)
 {
-    if (!c || !nmatches) return ORBX_ERR_INVALID;
-    *nmatches = 0;
-    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
-    if (M == 0 || N == 0) return ORBX_OK;
-    if (!kps || !desc || !mp_track_in_view || !mp_proj_x || !mp_proj_y || !mp_level || !mp_view_cos || !mp_desc ||
-        !mp_observations || !frame_obs || !frame_match || !match_score || (u_right && !mp_proj_xr))
-        return fail(c, ORBX_ERR_INVALID, "null buffer");
-    constexpr int kThHigh = 100;                      // TH_HIGH, src/ORBmatcher.cc:38
     const bool bFactor = th != 1.0;                   // :159
-    // the queries: map points in view that are not bad (:164-168), window r * mvScaleFactors[level] on levels
-    // [level - 1, level] (:173-179)
-    std::vector<int32_t> qi;
+    qi.clear();
     qi.reserve(M);
     for (int i = 0; i < M; i++) {
         if (!mp_track_in_view[i] || (mp_is_bad && mp_is_bad[i])) continue;
@@ -1811,8 +1805,12 @@ int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint3
         qi.push_back(i);
     }
     const int Q = (int)qi.size();
+    off.assign(1, 0);
+    idx.clear();
+    dist.clear();
+    rr.assign(Q, 0.0f);
     if (Q == 0) return ORBX_OK;
-    std::vector<float> qx(Q), qy(Q), qr(Q), rr(Q);
+    std::vector<float> qx(Q), qy(Q), qr(Q);
     std::vector<int32_t> qmin(Q), qmax(Q);
     std::vector<uint32_t> qd((size_t)Q * 8);
     for (int q = 0; q < Q; q++) {
@@ -1829,38 +1827,162 @@ int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint3
     }
     int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
     if (rc != ORBX_OK) return rc;
-    std::vector<int32_t> off, idx;
-    std::vector<uint16_t> dist;
-    rc = grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
-    if (rc != ORBX_OK) return rc;
+    return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+}
 
+// One map point against its candidate list: the scan and the accept step shared by SearchByProjection
+// (src/ORBmatcher.cc:186-237), SearchByProjection_Budget (:82-138), SearchByProjection_OnePoint and MatchCandidates
+// (include/ORBmatcher.h:94-148, :196-251).  Returns bestIdx; -1 when the best distance is above TH_HIGH (or nothing
+// was scanned), -2 when the ratio test rejected the best.
+static int projection_accept(const orbx_keypoint* kps, const float* u_right, const int32_t* idx, const uint16_t* dist, int n,
+                             float proj_xr, float r_scaled, float nnratio, int mp_index, int mp_observations,
+                             int32_t* frame_obs, int32_t* frame_match, int32_t* match_score)
+{
+    constexpr int kThHigh = 100;                      // TH_HIGH, src/ORBmatcher.cc:38
+    int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+    for (int k = 0; k < n; k++) {
+        const int i = idx[k];
+        if (frame_obs[i] > 0) continue;                                       // :197-199
+        if (u_right && u_right[i] > 0) {                                      // :201-206
+            const float er = fabsf(proj_xr - u_right[i]);
+            if (er > r_scaled) continue;
+        }
+        const int d = dist[k];
+        if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = kps[i].octave; bestIdx = i; }
+        else if (d < bestDist2) { bestLevel2 = kps[i].octave; bestDist2 = d; }
+    }
+    if (bestDist <= kThHigh) {                                                // :228
+        if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) return -2;   // :230-231
+        frame_match[bestIdx] = mp_index;                                      // :233
+        frame_obs[bestIdx] = mp_observations;
+        match_score[bestIdx] = bestDist;                                      // :235
+        return bestIdx;
+    }
+    return -1;
+}
+
+static int projection_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                             float min_x, float min_y, float inv_w, float inv_h, const uint8_t* mp_track_in_view,
+                             const uint8_t* mp_is_bad, const float* mp_proj_x, const float* mp_proj_y,
+                             const float* mp_proj_xr, const int32_t* mp_level, const float* mp_view_cos,
+                             const uint32_t* mp_desc, const int32_t* mp_observations, int M, float th, float nnratio,
+                             const double* time_constr_ms, int32_t* frame_obs, int32_t* frame_match, int32_t* match_score,
+                             int* nmatches, int* stopped_at)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();                         // timer.tic(), src/ORBmatcher.cc:54-55
+    *nmatches = 0;
+    if (stopped_at) *stopped_at = M;
+    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (M == 0 || N == 0) return ORBX_OK;
+    if (!kps || !desc || !mp_track_in_view || !mp_proj_x || !mp_proj_y || !mp_level || !mp_view_cos || !mp_desc ||
+        !mp_observations || !frame_obs || !frame_match || !match_score || (u_right && !mp_proj_xr))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    std::vector<int32_t> qi, off, idx;
+    std::vector<float> rr;
+    std::vector<uint16_t> dist;
+    int rc = projection_queries(c, kps, desc, N, min_x, min_y, inv_w, inv_h, mp_track_in_view, mp_is_bad, mp_proj_x,
+                                mp_proj_y, mp_level, mp_view_cos, mp_desc, M, th, qi, rr, off, idx, dist);
+    if (rc != ORBX_OK) return rc;
+    const int Q = (int)qi.size();
     int nm = 0;
     for (int q = 0; q < Q; q++) {
         const int iMP = qi[q];
         if (off[q + 1] == off[q]) continue;                                   // :181-182
-        const float r = rr[q];
-        const int lvl = mp_level[iMP];
-        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
-        for (int k = off[q]; k < off[q + 1]; k++) {
-            const int i = idx[k];
-            if (frame_obs[i] > 0) continue;                                   // :197-199
-            if (u_right && u_right[i] > 0) {                                  // :201-206
-                const float er = fabsf(mp_proj_xr[iMP] - u_right[i]);
-                if (er > r * c->p.scale[lvl]) continue;
+        const int got = projection_accept(kps, u_right, idx.data() + off[q], dist.data() + off[q], off[q + 1] - off[q],
+                                          mp_proj_xr ? mp_proj_xr[iMP] : 0.0f, rr[q] * c->p.scale[mp_level[iMP]], nnratio, iMP,
+                                          mp_observations[iMP], frame_obs, frame_match, match_score);
+        if (got >= 0) nm++;
+        else if (got == -2) continue;      // rejected by the ratio test: the reference's `continue` (:126-127) skips its clock
+        if (time_constr_ms) {
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (ms >= *time_constr_ms) {
+                if (stopped_at) *stopped_at = iMP;
+                break;
             }
-            const int d = dist[k];
-            if (d < bestDist) { bestDist2 = bestDist; bestDist = d; bestLevel2 = bestLevel; bestLevel = kps[i].octave; bestIdx = i; }
-            else if (d < bestDist2) { bestLevel2 = kps[i].octave; bestDist2 = d; }
-        }
-        if (bestDist <= kThHigh) {                                            // :228
-            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;   // :230-231
-            frame_match[bestIdx] = iMP;                                       // :233
-            frame_obs[bestIdx] = mp_observations[iMP];
-            match_score[bestIdx] = bestDist;                                  // :235
-            nm++;
         }
     }
     *nmatches = nm;
+    return ORBX_OK;
+}
+
+int orbx_search_by_projection(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                              float min_x, float min_y, float inv_w, float inv_h, const uint8_t* mp_track_in_view,
+                              const uint8_t* mp_is_bad, const float* mp_proj_x, const float* mp_proj_y,
+                              const float* mp_proj_xr, const int32_t* mp_level, const float* mp_view_cos,
+                              const uint32_t* mp_desc, const int32_t* mp_observations, int M, float th, float nnratio,
+                              int32_t* frame_obs, int32_t* frame_match, int32_t* match_score, int* nmatches)
+{
+    return projection_search(c, kps, desc, u_right, N, min_x, min_y, inv_w, inv_h, mp_track_in_view, mp_is_bad, mp_proj_x,
+                             mp_proj_y, mp_proj_xr, mp_level, mp_view_cos, mp_desc, mp_observations, M, th, nnratio, nullptr,
+                             frame_obs, frame_match, match_score, nmatches, nullptr);
+}
+
+int orbx_search_by_projection_budget(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                                     float min_x, float min_y, float inv_w, float inv_h, const uint8_t* mp_track_in_view,
+                                     const uint8_t* mp_is_bad, const float* mp_proj_x, const float* mp_proj_y,
+                                     const float* mp_proj_xr, const int32_t* mp_level, const float* mp_view_cos,
+                                     const uint32_t* mp_desc, const int32_t* mp_observations, int M, float th, float nnratio,
+                                     double time_constr_ms, int32_t* frame_obs, int32_t* frame_match, int32_t* match_score,
+                                     int* nmatches, int* stopped_at)
+{
+    return projection_search(c, kps, desc, u_right, N, min_x, min_y, inv_w, inv_h, mp_track_in_view, mp_is_bad, mp_proj_x,
+                             mp_proj_y, mp_proj_xr, mp_level, mp_view_cos, mp_desc, mp_observations, M, th, nnratio,
+                             &time_constr_ms, frame_obs, frame_match, match_score, nmatches, stopped_at);
+}
+
+int orbx_projection_candidates(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y,
+                               float inv_w, float inv_h, const uint8_t* mp_track_in_view, const uint8_t* mp_is_bad,
+                               const float* mp_proj_x, const float* mp_proj_y, const int32_t* mp_level,
+                               const float* mp_view_cos, const uint32_t* mp_desc, int M, float th, int32_t* cand_off,
+                               int32_t* cand_idx, uint16_t* cand_dist, int cap, int* total)
+{
+    if (!c || !total) return ORBX_ERR_INVALID;
+    *total = 0;
+    if (N < 0 || M < 0 || !cand_off) return fail(c, ORBX_ERR_INVALID, "bad arguments");
+    for (int i = 0; i <= M; i++) cand_off[i] = 0;
+    if (M == 0 || N == 0) return ORBX_OK;
+    if (!kps || !desc || !mp_track_in_view || !mp_proj_x || !mp_proj_y || !mp_level || !mp_view_cos || !mp_desc)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    std::vector<int32_t> qi, off, idx;
+    std::vector<float> rr;
+    std::vector<uint16_t> dist;
+    int rc = projection_queries(c, kps, desc, N, min_x, min_y, inv_w, inv_h, mp_track_in_view, mp_is_bad, mp_proj_x,
+                                mp_proj_y, mp_level, mp_view_cos, mp_desc, M, th, qi, rr, off, idx, dist);
+    if (rc != ORBX_OK) return rc;
+    // lists per map point: a point that asked for nothing has an empty one
+    const int Q = (int)qi.size();
+    int q = 0;
+    for (int i = 0; i < M; i++) {
+        cand_off[i] = off[q];
+        if (q < Q && qi[q] == i) q++;
+    }
+    cand_off[M] = off[Q];
+    *total = off[Q];
+    if (off[Q] == 0) return ORBX_OK;
+    if (!cand_idx || !cand_dist || cap < off[Q]) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
+    std::memcpy(cand_idx, idx.data(), (size_t)off[Q] * 4);
+    std::memcpy(cand_dist, dist.data(), (size_t)off[Q] * 2);
+    return ORBX_OK;
+}
+
+int orbx_match_candidates(orbx_ctx* c, const orbx_keypoint* kps, const float* u_right, int N, const int32_t* cand_idx,
+                          const uint16_t* cand_dist, int ncand, int track_in_view, int is_bad, float proj_xr, int level,
+                          float view_cos, float th, float nnratio, int mp_index, int mp_observations, int32_t* frame_obs,
+                          int32_t* frame_match, int32_t* match_score, int* best_idx)
+{
+    if (!c || !best_idx) return ORBX_ERR_INVALID;
+    *best_idx = -1;
+    if (!track_in_view || is_bad || ncand == 0) return ORBX_OK;              // include/ORBmatcher.h:176-183
+    if (ncand < 0 || !kps || !cand_idx || !cand_dist || !frame_obs || !frame_match || !match_score)
+        return fail(c, ORBX_ERR_INVALID, "bad arguments");
+    if (level < 0 || level >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "predicted level out of range");
+    for (int k = 0; k < ncand; k++)
+        if (cand_idx[k] < 0 || cand_idx[k] >= N) return fail(c, ORBX_ERR_INVALID, "candidate index outside the frame");
+    float r = view_cos > 0.998 ? 2.5f : 4.0f;                                 // :188
+    if (th != 1.0) r *= th;                                                   // :190-192
+    *best_idx = std::max(-1, projection_accept(kps, u_right, cand_idx, cand_dist, ncand, proj_xr, r * c->p.scale[level], nnratio,
+                                               mp_index, mp_observations, frame_obs, frame_match, match_score));
     return ORBX_OK;
 }
 

@@ -244,6 +244,76 @@ class ORBmatcher:
             frame_obs.ctypes.data, frame_match.ctypes.data, match_score.ctypes.data, C.byref(nm)))
         return nm.value
 
+    def SearchByProjection_Budget(self, keys, desc, mvuRight, grid, mp, th, time_constr, frame_obs, frame_match, match_score):
+        """ORBmatcher::SearchByProjection_Budget(F, vpMapPoints, th, time_constr) (src/ORBmatcher.cc:45-153):
+        SearchByProjection that stops once time_constr milliseconds have passed since the call was entered.
+        Returns (nmatches, index of the map point after which the loop ended, or M)."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        d = _desc(desc)
+        ur = None if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        for a in (frame_obs, frame_match, match_score):
+            if a.dtype != np.int32 or not a.flags.c_contiguous or len(a) < len(kps):
+                raise ValueError("frame arrays must be contiguous int32 arrays of N entries")
+        inview = np.ascontiguousarray(mp["mbTrackInView"], np.uint8)
+        bad = np.ascontiguousarray(mp["isBad"], np.uint8)
+        px, py, pxr, vc = (np.ascontiguousarray(mp[k], np.float32) for k in
+                           ("mTrackProjX", "mTrackProjY", "mTrackProjXR", "mTrackViewCos"))
+        lvl = np.ascontiguousarray(mp["mnTrackScaleLevel"], np.int32)
+        obs = np.ascontiguousarray(mp["Observations"], np.int32)
+        md = _desc(mp["descriptor"])
+        nm, stop = C.c_int32(), C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_projection_budget(
+            self._ctx, kps.ctypes.data, d.ctypes.data, ptr(ur), len(kps), grid[0], grid[1], grid[2], grid[3],
+            inview.ctypes.data, bad.ctypes.data, px.ctypes.data, py.ctypes.data, pxr.ctypes.data, lvl.ctypes.data,
+            vc.ctypes.data, md.ctypes.data, obs.ctypes.data, len(inview), float(th), self.mfNNratio, float(time_constr),
+            frame_obs.ctypes.data, frame_match.ctypes.data, match_score.ctypes.data, C.byref(nm), C.byref(stop)))
+        return nm.value, stop.value
+
+    def GetCandidates(self, keys, desc, grid, mp, th):
+        """ORBmatcher::GetCandidates (include/ORBmatcher.h:151-171) for every map point of mp in one device call, with
+        the descriptor distance of every candidate.  Returns (cand_off[M + 1], cand_idx, cand_dist): the list of map
+        point i is cand_idx[cand_off[i]:cand_off[i + 1]] (pMP->mvMatchCandidates)."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        d = _desc(desc)
+        inview = np.ascontiguousarray(mp["mbTrackInView"], np.uint8)
+        bad = np.ascontiguousarray(mp["isBad"], np.uint8)
+        px, py, vc = (np.ascontiguousarray(mp[k], np.float32) for k in ("mTrackProjX", "mTrackProjY", "mTrackViewCos"))
+        lvl = np.ascontiguousarray(mp["mnTrackScaleLevel"], np.int32)
+        md = _desc(mp["descriptor"])
+        M = len(inview)
+        off = np.zeros(M + 1, np.int32)
+        total = C.c_int32()
+        args = (self._ctx, kps.ctypes.data, d.ctypes.data, len(kps), grid[0], grid[1], grid[2], grid[3], inview.ctypes.data,
+                bad.ctypes.data, px.ctypes.data, py.ctypes.data, lvl.ctypes.data, vc.ctypes.data, md.ctypes.data, M, float(th),
+                off.ctypes.data)
+        rc = self._lib.orbx_projection_candidates(*args, None, None, 0, C.byref(total))
+        if rc == 0:                                   # no candidate at all
+            return off, np.zeros(0, np.int32), np.zeros(0, np.uint16)
+        if rc != -4:                                  # ORBX_ERR_CAPACITY is the answer to the sizing call
+            check(self._lib, self._ctx, rc)
+        idx = np.zeros(total.value, np.int32)
+        dist = np.zeros(total.value, np.uint16)
+        check(self._lib, self._ctx, self._lib.orbx_projection_candidates(*args, idx.ctypes.data, dist.ctypes.data,
+                                                                         total.value, C.byref(total)))
+        return off, idx, dist
+
+    def MatchCandidates(self, keys, mvuRight, cands, mp, i, th, frame_obs, frame_match, match_score):
+        """ORBmatcher::MatchCandidates (include/ORBmatcher.h:173-252) = SearchByProjection_OnePoint (:68-149) on the
+        list GetCandidates made: map point i of mp against the frame's current assignment.  Returns bestIdx or -1."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        ur = None if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        off, idx, dist = cands
+        a, b = int(off[i]), int(off[i + 1])
+        best = C.c_int32()
+        li, ld = idx[a:b], dist[a:b]
+        check(self._lib, self._ctx, self._lib.orbx_match_candidates(
+            self._ctx, kps.ctypes.data, ptr(ur), len(kps), li.ctypes.data if b > a else None,
+            ld.ctypes.data if b > a else None, b - a, int(mp["mbTrackInView"][i]), int(mp["isBad"][i]),
+            float(mp["mTrackProjXR"][i]), int(mp["mnTrackScaleLevel"][i]), float(mp["mTrackViewCos"][i]), float(th),
+            self.mfNNratio, int(i), int(mp["Observations"][i]), frame_obs.ctypes.data, frame_match.ctypes.data,
+            match_score.ctypes.data, C.byref(best)))
+        return best.value
+
     def SearchByProjectionLast(self, keys, desc, mvuRight, grid, last, th, mbf, bForward, bBackward, frame_obs, frame_match):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) (src/ORBmatcher.cc:1440-1593)
         from :1496 on.  last: dict of per-keypoint arrays of the last frame (visible, u, v, invzc, octave, angle,

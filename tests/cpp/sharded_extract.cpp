@@ -4,7 +4,9 @@
 //   sharded_extract <raw_u8_file> <w> <h> <nframes> <devices, e.g. 0,0,0> <out_file>
 // raw file: nframes frames back to back.  Prints "sharded ok: ..." when sharded == single for every frame.
 // out_file: int32 n1, nmatches; n1 x int32 vnMatches12; n1 x 2 float vbPrevMatched; then the last-frame projection
-// search of frame 0's keypoints in frame 1: int32 n2, nmatches; n2 x int32 frame_match; n2 x int32 frame_obs
+// search of frame 0's keypoints in frame 1: int32 n2, nmatches; n2 x int32 frame_match; n2 x int32 frame_obs; then
+// one-point matching of frame 0's keypoints as map points, last first: int32 ncandidates, nmatches; n2 x int32
+// frame_match; n2 x int32 mvpMatchScore
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -89,8 +91,29 @@ int main(int argc, char** argv)
             std::fwrite(hdr2, 4, 2, o);
             std::fwrite(fmatch.data(), 4, fmatch.size(), o);
             std::fwrite(fobs.data(), 4, fobs.size(), o);
+            // active matching (src/Observability.cc:1309-1329, :1404-1413): candidate lists of all map points at once, then
+            // one point at a time, here from the last map point to the first
+            orbx::MapPointsInView mp;
+            mp.mbTrackInView.assign(a.size(), 1);
+            mp.Observations.assign(a.size(), 1);
+            for (size_t i = 0; i < a.size(); i++) {
+                mp.mTrackProjX.push_back(a[i].x); mp.mTrackProjY.push_back(a[i].y); mp.mTrackProjXR.push_back(0.0f);
+                mp.mnTrackScaleLevel.push_back(a[i].octave); mp.mTrackViewCos.push_back(i % 2 ? 0.9995f : 0.9f);
+            }
+            mp.descriptors.assign(d2.begin(), d2.begin() + 32 * a.size());
+            orbx::ORBmatcher active(one, 0.8f, true);
+            const orbx::MatchCandidateTable table = active.GetCandidates(b, d2.data() + (size_t)cap * 32, grid, mp, 3.0f);
+            std::vector<int32_t> aobs(b.size(), -1), amatch(b.size(), -1), ascore(b.size(), -1);
+            int nm3 = 0;
+            for (size_t i = a.size(); i-- > 0;)
+                nm3 += active.SearchByProjection_OnePoint(b, nullptr, table, mp, i, 3.0f, aobs, amatch, ascore) >= 0;
+            int32_t hdr3[2] = {(int32_t)table.cand_idx.size(), nm3};
+            std::fwrite(hdr3, 4, 2, o);
+            std::fwrite(amatch.data(), 4, amatch.size(), o);
+            std::fwrite(ascore.data(), 4, ascore.size(), o);
             std::fclose(o);
-            std::printf("SearchForInitialization: %d matches, SearchByProjection(last frame): %d\n", nm, nm2);
+            std::printf("SearchForInitialization: %d matches, SearchByProjection(last frame): %d, one point at a time: %d\n", nm,
+                        nm2, nm3);
         }
     } catch (const std::exception& e) {
         std::fprintf(stderr, "%s\n", e.what());

@@ -109,6 +109,15 @@ class Oracle:
         lib.oo_search_by_projection_last.argtypes = [C.c_void_p, _u32p, _f32p, C.c_int, _f32p, C.c_float, C.c_float, C.c_float,
                                                      C.c_float, _u8p, _f32p, _f32p, _f32p, _i32p, _f32p, _u32p, _i32p,
                                                      C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, _i32p, _i32p]
+        _f, _ci = C.c_float, C.c_int
+        lib.oo_search_by_projection_budget.argtypes = [C.c_void_p, _u32p, _f32p, _ci, _f32p, _f, _f, _f, _f, _u8p, _u8p, _f32p,
+                                                       _f32p, _f32p, _i32p, _f32p, _u32p, _i32p, _ci, _f, _f, C.c_double,
+                                                       _i32p, _i32p, _i32p, _i32p]
+        lib.oo_get_candidates.argtypes = [C.c_void_p, _ci, _f32p, _f, _f, _f, _f, _ci, _ci, _f, _f, _ci, _f, _f, _i32p, _ci]
+        lib.oo_match_candidates.argtypes = [C.c_void_p, _u32p, _f32p, _f32p, _i32p, _ci, _ci, _ci, _f, _ci, _f, _u32p, _ci,
+                                            _ci, _f, _f, _i32p, _i32p, _i32p]
+        lib.oo_search_by_projection_one_point.argtypes = [C.c_void_p, _u32p, _f32p, _ci, _f32p, _f, _f, _f, _f, _ci, _ci, _f,
+                                                          _f, _f, _ci, _f, _u32p, _ci, _ci, _f, _f, _i32p, _i32p, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -387,6 +396,70 @@ class Oracle:
             _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3], _ptr(inview, _u8p), _ptr(bad, _u8p), _ptr(px, _f32p),
             _ptr(py, _f32p), _ptr(pxr, _f32p), _ptr(lvl, _i32p), _ptr(vc, _f32p), _ptr(md.view(np.uint32), _u32p),
             _ptr(obs, _i32p), len(inview), th, nnratio, _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
+            _ptr(match_score, _i32p))
+
+    def search_by_projection_budget(self, kps, desc, u_right, grid, mp, th, nnratio, time_constr, frame_obs, frame_match,
+                                    match_score):
+        """ORBmatcher::SearchByProjection_Budget; returns (nmatches, stopped_at)"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sf = self.tables()["scale"]
+        inview = np.ascontiguousarray(mp["mbTrackInView"], np.uint8)
+        bad = np.ascontiguousarray(mp["isBad"], np.uint8)
+        px, py, pxr, vc = (np.ascontiguousarray(mp[k], np.float32) for k in
+                           ("mTrackProjX", "mTrackProjY", "mTrackProjXR", "mTrackViewCos"))
+        lvl = np.ascontiguousarray(mp["mnTrackScaleLevel"], np.int32)
+        obs = np.ascontiguousarray(mp["Observations"], np.int32)
+        md = np.ascontiguousarray(mp["descriptor"], np.uint8).reshape(-1, 32)
+        stop = np.zeros(1, np.int32)
+        nm = self.lib.oo_search_by_projection_budget(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), len(kps),
+            _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3], _ptr(inview, _u8p), _ptr(bad, _u8p), _ptr(px, _f32p),
+            _ptr(py, _f32p), _ptr(pxr, _f32p), _ptr(lvl, _i32p), _ptr(vc, _f32p), _ptr(md.view(np.uint32), _u32p),
+            _ptr(obs, _i32p), len(inview), th, nnratio, float(time_constr), _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
+            _ptr(match_score, _i32p), _ptr(stop, _i32p))
+        return nm, int(stop[0])
+
+    def get_candidates(self, kps, grid, mp, i, th):
+        """ORBmatcher::GetCandidates for map point i -> pMP->mvMatchCandidates as an int32 array"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        sf = self.tables()["scale"]
+        out = np.zeros(max(len(kps), 1), np.int32)
+        n = self.lib.oo_get_candidates(kps.ctypes.data, len(kps), _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3],
+                                       int(mp["mbTrackInView"][i]), int(mp["isBad"][i]), float(mp["mTrackProjX"][i]),
+                                       float(mp["mTrackProjY"][i]), int(mp["mnTrackScaleLevel"][i]),
+                                       float(mp["mTrackViewCos"][i]), th, _ptr(out, _i32p), len(out))
+        return out[:n].copy()
+
+    def match_candidates(self, kps, desc, u_right, cand, mp, i, th, nnratio, frame_obs, frame_match, match_score):
+        """ORBmatcher::MatchCandidates for map point i on its stored list -> bestIdx or -1"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sf = self.tables()["scale"]
+        cand = np.ascontiguousarray(cand, np.int32)
+        md = np.ascontiguousarray(mp["descriptor"][i], np.uint8).reshape(32)
+        return self.lib.oo_match_candidates(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), _ptr(sf, _f32p),
+            _ptr(cand, _i32p) if len(cand) else None, len(cand), int(mp["mbTrackInView"][i]), int(mp["isBad"][i]),
+            float(mp["mTrackProjXR"][i]), int(mp["mnTrackScaleLevel"][i]), float(mp["mTrackViewCos"][i]),
+            _ptr(md.view(np.uint32), _u32p), int(mp["Observations"][i]), int(i), th, nnratio, _ptr(frame_obs, _i32p),
+            _ptr(frame_match, _i32p), _ptr(match_score, _i32p))
+
+    def search_by_projection_one_point(self, kps, desc, u_right, grid, mp, i, th, nnratio, frame_obs, frame_match, match_score):
+        """ORBmatcher::SearchByProjection_OnePoint for map point i -> bestIdx or -1"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        sf = self.tables()["scale"]
+        md = np.ascontiguousarray(mp["descriptor"][i], np.uint8).reshape(32)
+        return self.lib.oo_search_by_projection_one_point(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), len(kps),
+            _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3], int(mp["mbTrackInView"][i]), int(mp["isBad"][i]),
+            float(mp["mTrackProjX"][i]), float(mp["mTrackProjY"][i]), float(mp["mTrackProjXR"][i]),
+            int(mp["mnTrackScaleLevel"][i]), float(mp["mTrackViewCos"][i]), _ptr(md.view(np.uint32), _u32p),
+            int(mp["Observations"][i]), int(i), th, nnratio, _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
             _ptr(match_score, _i32p))
 
     def search_by_projection_last(self, kps, desc, u_right, grid, last, th, mbf, forward, backward, check_ori,

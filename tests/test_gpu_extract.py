@@ -470,6 +470,21 @@ def test_cpp_sharded_extractor_and_matcher(oracle, euroc_left, euroc_right, tmp_
     assert n2 == len(k2) and nm2 == nm_o2 and nm2 > 20
     assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8), fm)
     assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8 + 4 * n2), fo)
+    # orbx::ORBmatcher::GetCandidates + SearchByProjection_OnePoint, last map point first
+    off += 8 + 8 * n2
+    ncand, nm3 = np.frombuffer(buf, np.int32, 2, off)
+    M = len(k1)
+    mp = {"mbTrackInView": np.ones(M, np.uint8), "isBad": np.zeros(M, np.uint8), "mTrackProjX": k1["x"].copy(),
+          "mTrackProjY": k1["y"].copy(), "mTrackProjXR": np.zeros(M, np.float32),
+          "mnTrackScaleLevel": k1["octave"].astype(np.int32),
+          "mTrackViewCos": np.where(np.arange(M) % 2, np.float32(0.9995), np.float32(0.9)).astype(np.float32),
+          "Observations": np.ones(M, np.int32), "descriptor": d1}
+    fo, fm, ms = (np.full(len(k2), -1, np.int32) for _ in range(3))
+    rets = [oracle.search_by_projection_one_point(k2, d2, None, grid, mp, i, 3.0, 0.8, fo, fm, ms) for i in range(M - 1, -1, -1)]
+    assert ncand == sum(len(oracle.get_candidates(k2, grid, mp, i, 3.0)) for i in range(M))
+    assert nm3 == sum(r >= 0 for r in rets) and nm3 > 20
+    assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8), fm)
+    assert np.array_equal(np.frombuffer(buf, np.int32, n2, off + 8 + 4 * n2), ms)
 
 
 def test_cpp_adapter_program(euroc_left, tmp_path):

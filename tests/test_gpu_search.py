@@ -255,3 +255,72 @@ def test_last_frame_projection_search_with_collisions(matcher, oracle, seed, ste
     hidden = dict(last, visible=np.zeros(len(last["u"]), np.uint8))
     assert _both_projection_last(matcher, oracle, kps, desc, u_right, hidden, th, 40.0, fwd, bwd, True, obs0)[0] == 0
     assert _both_projection_last(matcher, oracle, kps[:0], desc[:0], None, last, th, 40.0, fwd, bwd, True, obs0[:0])[0] == 0
+
+
+# ---- the good-feature forms (include/ORBmatcher.h:68-252, src/ORBmatcher.cc:45-153) ----
+@pytest.mark.parametrize("seed,stereo,th", [(41, False, 1.0), (42, True, 3.0), (43, True, 1.0)])
+def test_candidate_table_and_one_point_matching(matcher, oracle, seed, stereo, th):
+    """GetCandidates for all map points in one device call (lists + distances), then MatchCandidates /
+    SearchByProjection_OnePoint per point in the order an active-matching heap would draw them
+    (src/Observability.cc:1309-1329, :1404-1413): every list, every distance, every return value and the frame's
+    assignment after every call equal the oracle's."""
+    from orb_slam_amd import ORBmatcher
+    from test_oracle_search import _fresh, _gf_case
+    rng, kps, desc, sf, mp, u_right, obs0 = _gf_case(oracle, seed, stereo, n=3000, m=2500)
+    m = ORBmatcher(matcher._ex, nnratio=0.8)
+    M = len(mp["isBad"])
+    cands = m.GetCandidates(kps, desc, GRID, mp, th)
+    off, idx, dist = cands
+    assert off[0] == 0 and off[M] == len(idx) == len(dist) and len(idx) > 2000
+    for i in range(0, M, 7):
+        want = oracle.get_candidates(kps, GRID, mp, i, th)
+        assert np.array_equal(idx[off[i]:off[i + 1]], want)
+        if len(want):
+            d = np.unpackbits(desc[want] ^ mp["descriptor"][i][None, :], axis=1).sum(1)
+            assert np.array_equal(dist[off[i]:off[i + 1]], d.astype(np.uint16))
+    order = rng.permutation(M)
+    got, ref = _fresh(obs0), _fresh(obs0)
+    for n, i in enumerate(order):
+        a = m.MatchCandidates(kps, u_right, cands, mp, int(i), th, *got)
+        b = oracle.search_by_projection_one_point(kps, desc, u_right, GRID, mp, int(i), th, 0.8, *ref)
+        assert a == b, (n, i)
+    for x, y in zip(got, ref):
+        assert np.array_equal(x, y)
+    assert (got[1] >= 0).sum() > 200
+    # nothing in view, nothing at all
+    hidden = dict(mp, mbTrackInView=np.zeros(M, np.uint8))
+    off0, idx0, _ = m.GetCandidates(kps, desc, GRID, hidden, th)
+    assert len(idx0) == 0 and (off0 == 0).all()
+    assert m.MatchCandidates(kps, u_right, (off0, idx0, idx0.astype(np.uint16)), hidden, 3, th, *got) == -1
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(51, False, 1.0), (52, True, 3.0)])
+def test_budgeted_projection_search(matcher, oracle, seed, stereo, th):
+    """SearchByProjection_Budget (src/Tracking.cc:2240): with a budget that is never reached the result of
+    SearchByProjection, with none the first map point that reaches the clock; in between any prefix of the loop, which
+    is what the wall clock of the reference yields too."""
+    from orb_slam_amd import ORBmatcher
+    from test_oracle_search import _fresh, _gf_case
+    rng, kps, desc, sf, mp, u_right, obs0 = _gf_case(oracle, seed, stereo, n=3000, m=2500)
+    m = ORBmatcher(matcher._ex, nnratio=0.8)
+    M = len(mp["isBad"])
+    mp["mbTrackInView"][0] = 0
+    mp["isBad"][1] = 1
+    mp["mTrackProjX"][2] = 5000.0
+    for budget in (1e12, 0.0):
+        got, ref = _fresh(obs0), _fresh(obs0)
+        a = m.SearchByProjection_Budget(kps, desc, u_right, GRID, mp, th, budget, *got)
+        b = oracle.search_by_projection_budget(kps, desc, u_right, GRID, mp, th, 0.8, budget, *ref)
+        assert a == b
+        assert a[1] == M if budget > 0 else 3 <= a[1] < M
+        for x, y in zip(got, ref):
+            assert np.array_equal(x, y)
+    # a budget in between: the loop ended after map point `stop`, and the result is that of the loop over [0, stop]
+    got, ref = _fresh(obs0), _fresh(obs0)
+    nm, stop = m.SearchByProjection_Budget(kps, desc, u_right, GRID, mp, th, 0.3, *got)
+    pre = {k: v[:stop + 1] for k, v in mp.items()}
+    nm_ref = oracle.search_by_projection(kps, desc, u_right, GRID, pre, th, 0.8, *ref)
+    if stop < M:
+        assert nm == nm_ref
+        for x, y in zip(got, ref):
+            assert np.array_equal(x, y)

@@ -280,9 +280,18 @@ def _map_points(rng, kps, desc, M, sf):
     return mp
 
 
-def _py_search_by_projection(kps, desc, u_right, grid, mp, th, nnratio, sf, frame_obs, frame_match, match_score):
+def _py_search_by_projection(kps, desc, u_right, grid, mp, th, nnratio, sf, frame_obs, frame_match, match_score,
+                             order=None, budget0=False, extra=None):
+    """order: the map points to visit (default: all, ascending -- the loop of SearchByProjection; any other order is a
+    sequence of SearchByProjection_OnePoint calls); budget0: end after the first point that reaches the end of the loop
+    body (SearchByProjection_Budget with no time at all); extra: dict that receives 'returns' (bestIdx or -1 per visited
+    point) and 'stopped_at'"""
     nm = 0
-    for i in range(len(mp["mbTrackInView"])):
+    if extra is not None:
+        extra["returns"], extra["stopped_at"] = [], len(mp["mbTrackInView"])
+    for i in (range(len(mp["mbTrackInView"])) if order is None else order):
+        if extra is not None:
+            extra["returns"].append(-1)
         if not mp["mbTrackInView"][i] or mp["isBad"][i]:
             continue
         lvl = int(mp["mnTrackScaleLevel"][i])
@@ -291,6 +300,8 @@ def _py_search_by_projection(kps, desc, u_right, grid, mp, th, nnratio, sf, fram
             r = np.float32(r * np.float32(th))
         win = np.float32(r * sf[lvl])
         cands = _py_features_in_area(kps, grid, mp["mTrackProjX"][i], mp["mTrackProjY"][i], win, lvl - 1, lvl)
+        if len(cands) == 0:
+            continue
         best, best2, bl, bl2, bi = 256, 256, -1, -1, -1
         for idx in cands:
             if frame_obs[idx] > 0:
@@ -310,6 +321,12 @@ def _py_search_by_projection(kps, desc, u_right, grid, mp, th, nnratio, sf, fram
             frame_obs[bi] = mp["Observations"][i]
             match_score[bi] = best
             nm += 1
+            if extra is not None:
+                extra["returns"][-1] = int(bi)
+        if budget0:
+            if extra is not None:
+                extra["stopped_at"] = i
+            break
     return nm
 
 
@@ -520,3 +537,76 @@ def test_last_frame_projection_search_rules(oracle):
     fo, fm = np.full(12, -1, np.int32), np.full(12, -1, np.int32)
     assert oracle.search_by_projection_last(kq, dq, None, GRID, last, 3.0, 40.0, False, False, True, fo, fm) == 11
     assert fm.tolist() == list(range(11)) + [-1] and fo.tolist() == [1] * 11 + [-1]
+
+
+# ---- the good-feature forms: SearchByProjection_OnePoint / GetCandidates + MatchCandidates (include/ORBmatcher.h:68-252),
+# ---- SearchByProjection_Budget (src/ORBmatcher.cc:45-153)
+def _gf_case(oracle, seed, stereo, n=400, m=300):
+    rng = np.random.default_rng(300 + seed)
+    kps, desc, _, _ = _random_frames(rng, n, 1, clusters=8)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    sf = oracle.tables()["scale"]
+    mp = _map_points(rng, kps, desc, m, sf)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.random(len(kps)).astype(np.float32) * 30, -1).astype(np.float32)
+    obs0 = rng.choice([-1, -1, -1, 0, 2], len(kps)).astype(np.int32)
+    return rng, kps, desc, sf, mp, u_right, obs0
+
+
+def _fresh(obs0):
+    return obs0.copy(), np.full(len(obs0), -1, np.int32), np.full(len(obs0), -1, np.int32)
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(1, False, 1.0), (2, True, 3.0), (3, True, 1.0)])
+def test_one_point_forms_in_any_order(oracle, seed, stereo, th):
+    """The active-matching loop of the reference draws map points in the order of its heap (src/Observability.cc:
+    1404-1413): SearchByProjection_OnePoint per drawn point, each seeing what the earlier ones assigned.  In ascending
+    order the calls add up to SearchByProjection; in a shuffled order they equal the Python statement run in that
+    order; GetCandidates + MatchCandidates equal SearchByProjection_OnePoint."""
+    rng, kps, desc, sf, mp, u_right, obs0 = _gf_case(oracle, seed, stereo)
+    M = len(mp["isBad"])
+    ref = _fresh(obs0)
+    nm_ref = oracle.search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, *ref)
+    one = _fresh(obs0)
+    rets = [oracle.search_by_projection_one_point(kps, desc, u_right, GRID, mp, i, th, 0.8, *one) for i in range(M)]
+    assert sum(r >= 0 for r in rets) == nm_ref and nm_ref > 30
+    for a, b in zip(ref, one):
+        assert np.array_equal(a, b)
+    order = rng.permutation(M)[: M * 2 // 3]
+    shuffled, split, py = _fresh(obs0), _fresh(obs0), _fresh(obs0)
+    r1 = [oracle.search_by_projection_one_point(kps, desc, u_right, GRID, mp, int(i), th, 0.8, *shuffled) for i in order]
+    r2 = []
+    for i in order:
+        cand = oracle.get_candidates(kps, GRID, mp, int(i), th)
+        r2.append(oracle.match_candidates(kps, desc, u_right, cand, mp, int(i), th, 0.8, *split))
+    extra = {}
+    _py_search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, sf, *py, order=[int(i) for i in order], extra=extra)
+    assert r1 == r2 == extra["returns"]
+    for a, b, c in zip(shuffled, split, py):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert not all(np.array_equal(a, b) for a, b in zip(shuffled, ref))      # the order did matter
+
+
+@pytest.mark.parametrize("seed,stereo,th", [(5, False, 1.0), (6, True, 3.0)])
+def test_budgeted_projection_search_at_its_two_deterministic_ends(oracle, seed, stereo, th):
+    rng, kps, desc, sf, mp, u_right, obs0 = _gf_case(oracle, seed, stereo)
+    M = len(mp["isBad"])
+    ref, never = _fresh(obs0), _fresh(obs0)
+    nm_ref = oracle.search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, *ref)
+    nm, stop = oracle.search_by_projection_budget(kps, desc, u_right, GRID, mp, th, 0.8, 1e12, *never)
+    assert (nm, stop) == (nm_ref, M)
+    for a, b in zip(ref, never):
+        assert np.array_equal(a, b)
+    # no time at all: the loop ends after the first map point that reaches the clock -- not one that is out of view,
+    # bad, without candidates or rejected by the ratio test.  Make the first points such cases.
+    mp["mbTrackInView"][0] = 0
+    mp["isBad"][1] = 1
+    mp["mTrackProjX"][2] = 5000.0
+    zero, py = _fresh(obs0), _fresh(obs0)
+    extra = {}
+    nm0, stop0 = oracle.search_by_projection_budget(kps, desc, u_right, GRID, mp, th, 0.8, 0.0, *zero)
+    nm_py = _py_search_by_projection(kps, desc, u_right, GRID, mp, th, 0.8, sf, *py, budget0=True, extra=extra)
+    assert (nm0, stop0) == (nm_py, extra["stopped_at"]) and 3 <= stop0 < M and nm0 <= 1
+    for a, b in zip(zero, py):
+        assert np.array_equal(a, b)

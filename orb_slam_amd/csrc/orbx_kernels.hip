@@ -1085,6 +1085,47 @@ __device__ __forceinline__ int block_excl_scan(int v, int* tmp, int* total)
     return base + incl - v;
 }
 
+// The same with one barrier: tmp must not be the array the workgroup's previous scan used (the callers alternate
+// between two), so that nobody still reads what this call writes.
+template <int NT>
+__device__ __forceinline__ int block_excl_scan1(int v, int* tmp, int* total)
+{
+    const int incl = wave_incl_scan(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) tmp[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        const int t = tmp[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + incl - v;
+}
+// two values per thread, one barrier; tmp = 2 * NT / 64 ints
+template <int NT>
+__device__ __forceinline__ void block_excl_scan1_pair(int va, int vb, int* tmp, int* base_a, int* base_b, int* tot_a, int* tot_b)
+{
+    const int ia = wave_incl_scan(va), ib = wave_incl_scan(vb);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 63) { tmp[w] = ia; tmp[NT / 64 + w] = ib; }
+    __syncthreads();
+    int ba = 0, bb = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) {
+        const int x = tmp[i], y = tmp[NT / 64 + i];
+        if (i < w) { ba += x; bb += y; }
+        ta += x;
+        tb += y;
+    }
+    *tot_a = ta;
+    *tot_b = tb;
+    *base_a = ba + ia - va;
+    *base_b = bb + ib - vb;
+}
+
 // in-place exclusive scan of an LDS array; returns the total to every thread
 template <int NT>
 __device__ __forceinline__ int lds_excl_scan(int* a, int n, int* tmp)
@@ -1174,7 +1215,7 @@ __device__ __forceinline__ void wave_count(int* ctr, int idx)
 __host__ __device__ inline size_t quadtree_fixed_lds(int M_)
 {
     const size_t M = (size_t)M_;
-    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 64 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
+    return (2 * M * 8 + 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 96 * 4 + 2 * M * 2 + 4 * M * 2 + 3 * M * 2 + M + 64 + 15) & ~(size_t)15;
 }
 constexpr int kKeyRegsWide = 3;   // register keys per thread of the 1024-thread shape (3072 keys per level)
 constexpr int kKeyRegs = 10;   // keys per thread held in registers (10 * 256 = 2560 keys per level); 91 VGPRs = 5 wavefronts per SIMD. 16 keys cost 210 VGPRs (2 per SIMD) and 40 % of the time
@@ -1252,11 +1293,33 @@ __global__ __launch_bounds__(256) void k_qt_bins(FrameGeom g, CountLevels cl, co
 __host__ __device__ inline size_t qt_counts_lds(int M_)
 {
     const size_t M = (size_t)M_;
-    return 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 64 * 4 + 2 * M * 4 + 2 * M * 2 + 2 * M * 2 + 2 * M + M + 64;
+    return 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 96 * 4 + 2 * M * 4 + 2 * M * 2 + 2 * M * 2 + 2 * M + M + 64;
 }
 
 // Returns true when the level is done; false (nothing written) when a node at the leaves' depth would have to be
 // split, and the caller then runs the passes over the keys.  Uniform over the workgroup.  smem: qt_counts_lds(M) bytes.
+#ifdef ORBX_QT_TIMING
+// diagnostic build only: wall-clock marks (100 MHz) of every (frame, level) workgroup of the quadtree kernels
+__device__ unsigned long long g_qt_timing[64 * 8 * 8];
+#define QT_MARK(sec) do { if (threadIdx.x == 0) g_qt_timing[((blockIdx.x & 63) * 8 + (blockIdx.y & 7)) * 8 + (sec)] = wall_clock64(); } while (0)
+#define QT_NOTE(sec, v) do { if (threadIdx.x == 0) g_qt_timing[((blockIdx.x & 63) * 8 + (blockIdx.y & 7)) * 8 + (sec)] = (unsigned long long)(v); } while (0)
+__device__ unsigned long long g_qt_step[64 * 8 * 8];     // time per stretch of a step, summed over the steps of the workgroup
+#define QT_STEP_DECL unsigned long long qt_last_ = 0, qt_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int qt_steps_ = 0; const unsigned long long qt_c0_ = clock64(), qt_w0_ = wall_clock64(); if (threadIdx.x == 0) qt_last_ = wall_clock64()
+#define QT_STEP(k) do { if (threadIdx.x == 0) { const unsigned long long now_ = wall_clock64(); qt_acc_[k] += now_ - qt_last_; qt_last_ = now_; } } while (0)
+#define QT_STEP_END() do { qt_steps_++; } while (0)
+#define QT_STEP_FLUSH() do { qt_acc_[6] = clock64() - qt_c0_; qt_acc_[7] = wall_clock64() - qt_w0_; if (threadIdx.x == 0) { for (int k_ = 0; k_ < 8; k_++) g_qt_step[((blockIdx.x & 63) * 8 + (blockIdx.y & 7)) * 8 + k_] = qt_acc_[k_]; \
+                                                     g_qt_timing[((blockIdx.x & 63) * 8 + (blockIdx.y & 7)) * 8 + 7] = (unsigned long long)qt_steps_; } } while (0)
+extern "C" int orbx_debug_qt_timing(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_timing), sizeof(g_qt_timing)); }
+extern "C" int orbx_debug_qt_steps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_step), sizeof(g_qt_step)); }
+#else
+#define QT_MARK(sec)
+#define QT_NOTE(sec, v)
+#define QT_STEP_DECL
+#define QT_STEP(k)
+#define QT_STEP_END()
+#define QT_STEP_FLUSH()
+#endif
+
 template <int NT>
 __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const CountLevels& cl, int slot, int level, int f,
                                                      const uint32_t* __restrict__ cell_cand, uint2* __restrict__ kp_stage,
@@ -1272,8 +1335,8 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
     int* s_B = s_A + M;                                                // M
     int* s_C = s_B + M;                                                // M
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                // M (only while ranking)
-    int* s_var = s_C + M;                                              // 64
-    int* s_path = s_var + 64;                                          // 2*M
+    int* s_var = s_C + M;                                              // 96
+    int* s_path = s_var + 96;                                          // 2*M
     short* s_cidx = reinterpret_cast<short*>(s_path + 2 * M);          // 2*M
     unsigned short* s_order = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);   // M
     unsigned short* s_cand = s_order + M;                              // M
@@ -1296,6 +1359,7 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
         }
         __syncthreads();
     }
+    QT_MARK(2);
     // ---- root nodes (:492-534)
     for (int r = tid; r < nIni; r += NT) { s_A[r] = H[r]; s_B[r] = H[r] > 0; }
     if (tid == 0) {
@@ -1317,7 +1381,11 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; s_var[8] = 0; }
     __syncthreads();
 
-    // ---- splitting steps: as in quadtree_body, the child occupancy read from the sums
+    // ---- splitting steps: as in quadtree_body (a thread owns runs of list positions and of the processing order),
+    // the child occupancy read from the sums
+    int* const s_tmpA = s_var + 16;     // scan scratch, two arrays used in turn (32 ints each)
+    int* const s_tmpB = s_var + 48;
+    QT_STEP_DECL;
     while (true) {
         size = s_var[4];
         const int phase2 = s_var[5];
@@ -1329,39 +1397,45 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
         int* pa_nxt = s_path + (cur ^ 1) * M;
         unsigned char* de_cur = s_depth + cur * M;
         unsigned char* de_nxt = s_depth + (cur ^ 1) * M;
+        const int cp = (size + NT - 1) / NT;
+        const int p0 = min(tid * cp, size), p1 = min(p0 + cp, size);
 
-        for (int p = tid; p < size; p += NT) {
+        int nf = 0;
+        for (int p = p0; p < p1; p++) {
             const int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
             s_fl[p] = (unsigned char)e;
-            s_A[p] = e;
+            nf += e;
             int4 occ = make_int4(0, 0, 0, 0);
             if (e) {
                 const int d = de_cur[p];
                 if (d >= D) s_var[8] = 1;
                 else occ = *reinterpret_cast<const int4*>(H + qt_depth_off(nIni, d + 1) + 4 * pa_cur[p]);
             }
-            s_cc[4 * p] = occ.x; s_cc[4 * p + 1] = occ.y; s_cc[4 * p + 2] = occ.z; s_cc[4 * p + 3] = occ.w;
+            *reinterpret_cast<int4*>(&s_cc[4 * p]) = occ;
         }
         if (tid == 0) s_var[7] = 0;
-        __syncthreads();
+        int m;
+        int fpos = block_excl_scan1<NT>(nf, s_tmpA, &m);
+        QT_STEP(0);
         if (s_var[8]) {                                    // deeper than the leaves: the passes over the keys take this level
             __syncthreads();
             return false;
         }
-        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
-        if (!phase2) {
-            for (int p = tid; p < size; p += NT)
-                if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
-            __syncthreads();
-        } else {
-            const int m = norder;
-            for (int p = tid; p < size; p += NT)
-                if (s_fl[p]) {
-                    s_cand[s_A[p]] = (unsigned short)p;
-                    s_key[s_A[p]] = (uint32_t)cc_cur[p];
-                    s_B[s_A[p]] = ci_cur[p];
+        for (int p = p0; p < p1; p++)
+            if (s_fl[p]) {
+                if (!phase2) {
+                    s_order[fpos] = (unsigned short)p;
+                } else {
+                    s_cand[fpos] = (unsigned short)p;
+                    s_key[fpos] = (uint32_t)cc_cur[p];
+                    s_B[fpos] = ci_cur[p];
                 }
-            __syncthreads();
+                fpos++;
+            }
+        __syncthreads();
+        QT_STEP(1);
+        int norder = m;
+        if (phase2) {
             // rank in (size, creation) descending order: G lanes share one candidate's m comparisons
             int G = 1;
             while (G < 64 && m * (2 * G) <= NT) G *= 2;
@@ -1380,44 +1454,55 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
                 if (i < m && sub == 0) s_order[r] = s_cand[i];
             }
             __syncthreads();
-            for (int s = tid; s < m; s += NT) {
-                const int p = s_order[s];
-                s_B[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0) - 1;
-                s_C[s] = s_B[s];
+            const int cs = (m + NT - 1) / NT;
+            const int s0 = min(tid * cs, m), s1 = min(s0 + cs, m);
+            int gsum = 0;
+            for (int s_ = s0; s_ < s1; s_++) {
+                const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
+                gsum += (occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0) - 1;
             }
-            __syncthreads();
-            lds_excl_scan<NT>(s_C, m, s_tmp);
+            int gtot;
+            int gpos = block_excl_scan1<NT>(gsum, s_tmpB, &gtot);
             int below = 0;
-            for (int s = tid; s < m; s += NT) below += (size + s_C[s] + s_B[s] < N);
+            for (int s_ = s0; s_ < s1; s_++) {
+                const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
+                const int gr = (occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0) - 1;
+                below += (size + gpos + gr < N);
+                gpos += gr;
+            }
             if (below) atomicAdd(&s_var[7], below);
             __syncthreads();
             norder = min(s_var[7] + 1, m);
-            for (int p = tid; p < size; p += NT) s_fl[p] = 0;
+            for (int s_ = s0; s_ < s1; s_++) s_fl[s_order[s_]] = (unsigned char)(s_ < norder);
             __syncthreads();
-            for (int s = tid; s < norder; s += NT) s_fl[s_order[s]] = 1;
-            __syncthreads();
+            QT_STEP(2);
         }
-        for (int s = tid; s < norder; s += NT) {
-            const int p = s_order[s];
-            s_A[s] = ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) |
-                     (((s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1)) << 16);
+        const int co = (norder + NT - 1) / NT;
+        const int o0 = min(tid * co, norder), o1 = min(o0 + co, norder);
+        int sum_par = 0, nu = 0;
+        for (int s_ = o0; s_ < o1; s_++) {
+            const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
+            sum_par += ((occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0)) |
+                       (((occ.x > 1) + (occ.y > 1) + (occ.z > 1) + (occ.w > 1)) << 16);
         }
-        for (int p = tid; p < size; p += NT) s_C[p] = !s_fl[p];
-        __syncthreads();
-        int both, nold;
-        lds_excl_scan2<NT>(s_A, norder, s_C, size, s_tmp, &both, &nold);
+        for (int p = p0; p < p1; p++) nu += !s_fl[p];
+        int par_pos, old_pos, both, nold;
+        block_excl_scan1_pair<NT>(sum_par, nu, phase2 ? s_tmpA : s_tmpB, &par_pos, &old_pos, &both, &nold);
+        QT_STEP(3);
         const int totalch = both & 0xffff, ncreated = both >> 16;
         const int newsize = totalch + nold;
-        for (int s = tid; s < norder; s += NT) {
-            const int p = s_order[s];
-            const int nch = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
-            int pos = totalch - ((s_A[s] & 0xffff) + nch);   // children of later parents come first
-            int cb = s_A[s] >> 16;
+        for (int s_ = o0; s_ < o1; s_++) {
+            const int p = s_order[s_];
+            const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * p]);
+            const int oc[4] = {occ.x, occ.y, occ.z, occ.w};
+            const int nch = (oc[0] > 0) + (oc[1] > 0) + (oc[2] > 0) + (oc[3] > 0);
+            int pos = totalch - ((par_pos & 0xffff) + nch);   // children of later parents come first
+            int cb = par_pos >> 16;
             int cpos[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int qd = 3; qd >= 0; qd--)
-                if (s_cc[4 * p + qd] > 0) {
-                    cn_nxt[pos] = s_cc[4 * p + qd];
+                if (oc[qd] > 0) {
+                    cn_nxt[pos] = oc[qd];
                     ci_nxt[pos] = -1;
                     pa_nxt[pos] = 4 * pa_cur[p] + qd;
                     de_nxt[pos] = (unsigned char)(de_cur[p] + 1);
@@ -1426,11 +1511,12 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
                 }
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
-                if (s_cc[4 * p + qd] > 1) ci_nxt[cpos[qd]] = (short)(cb++);
+                if (oc[qd] > 1) ci_nxt[cpos[qd]] = (short)(cb++);
+            par_pos += nch | (((oc[0] > 1) + (oc[1] > 1) + (oc[2] > 1) + (oc[3] > 1)) << 16);
         }
-        for (int p = tid; p < size; p += NT)
+        for (int p = p0; p < p1; p++)
             if (!s_fl[p]) {
-                const int pos = totalch + s_C[p];
+                const int pos = totalch + old_pos++;
                 cn_nxt[pos] = cc_cur[p];
                 ci_nxt[pos] = -1;
                 pa_nxt[pos] = pa_cur[p];
@@ -1443,9 +1529,14 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
         }
         cur ^= 1;
         __syncthreads();
+        QT_STEP(4);
+        QT_STEP_END();
         if (s_var[6]) break;
     }
 
+    QT_STEP_FLUSH();
+    QT_MARK(3);
+    QT_NOTE(5, 0);
     // ---- best key of every node (:689-710): the maximum over its leaves, decoded from the candidate slot
     size = s_var[4];
     const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
@@ -1460,6 +1551,7 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
         stage[p] = make_uint2((uint32_t)x | ((uint32_t)y << 16), (uint32_t)(b >> 32));
     }
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
+    QT_MARK(4);
     return true;
 }
 
@@ -1489,6 +1581,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         if (tid == 0) { level_count[f * kMaxLevels + level] = 0; level_ncand[f * kMaxLevels + level] = 0; }
         return;
     }
+    QT_MARK(0);
     // A level with many times more candidates than features to keep runs on node counts (k_qt_bins has filled the
     // leaves): its tree stays shallow.  The passes over the keys below serve it only if the tree grows deeper than the
     // leaves after all; a level that keeps most of its candidates splits down to single keys and goes there directly.
@@ -1499,6 +1592,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         for (int c = tid; c < ncells; c += NT) part += cnts[c];
         (void)block_excl_scan<NT>(part, reinterpret_cast<int*>(smem_lds), &total);
         __syncthreads();
+        QT_MARK(1);
+        QT_NOTE(6, total);
         if (total >= cl.min_ratio * L.nfeat &&
             quadtree_counts_body<NT>(g, cl, cl.slot[level], level, f, cell_cand, kp_stage, level_count, level_ncand, count_scratch, smem_lds))
             return;
@@ -1513,8 +1608,8 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     int* s_B = s_A + M;                                                                 // M
     int* s_C = s_B + M;                                                                 // M
     uint32_t* s_key = reinterpret_cast<uint32_t*>(s_C);                                 // M (only while ranking)
-    int* s_var = s_C + M;                                                               // 64
-    short* s_cidx = reinterpret_cast<short*>(s_var + 64);                               // 2*M
+    int* s_var = s_C + M;                                                               // 96
+    short* s_cidx = reinterpret_cast<short*>(s_var + 96);                               // 2*M
     unsigned short* s_childpos = reinterpret_cast<unsigned short*>(s_cidx + 2 * M);     // 4*M
     unsigned short* s_order = s_childpos + 5 * M;                                       // M (M entries before it are unused)
     unsigned short* s_cand = s_order + M;                                               // M
@@ -1564,6 +1659,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         __syncthreads();
     }
     if (tid == 0) level_ncand[f * kMaxLevels + level] = n;
+    QT_MARK(1);
+    QT_NOTE(6, n);
+    QT_NOTE(5, 1);
 
     // The first KR*NT keys live in registers (coordinates, response and current node);
     // only the rare overflow beyond that walks the global arrays.  FOR_KEYS(body) runs body
@@ -1689,8 +1787,15 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     if (tid == 0) { s_var[4] = size; s_var[5] = 0; s_var[6] = 0; }
     __syncthreads();
 
+    QT_MARK(2);
     const bool packed_rank = NB == 11 && n < (1 << 19);   // the packed key holds creation indices below 4 * 2048
-    // ---- splitting steps
+    // ---- splitting steps.  A thread owns a run of consecutive list positions and a run of consecutive places in the
+    // processing order, so that the scans of a step need only the other threads' totals: five barriers per step while
+    // every multi-key node is split, nine in the size-ordered sweeps (each stretch between two barriers costs about
+    // as much as the others, whatever the number of nodes).
+    int* const s_tmpA = s_var + 16;     // scan scratch, two arrays used in turn (32 ints each)
+    int* const s_tmpB = s_var + 48;
+    QT_STEP_DECL;
     while (true) {
         size = s_var[4];
         const int phase2 = s_var[5];
@@ -1700,19 +1805,35 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         int* cn_nxt = s_cnt + (cur ^ 1) * M;
         short* ci_cur = s_cidx + cur * M;
         short* ci_nxt = s_cidx + (cur ^ 1) * M;
+        const int cp = (size + NT - 1) / NT;
+        const int p0 = min(tid * cp, size), p1 = min(p0 + cp, size);
 
-        // a. nodes that may be split in this step; clear child counts
-        for (int p = tid; p < size; p += NT) {
-            int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
+        // a. nodes that may be split in this step; clear child counts; their index among the flagged nodes in list order
+        int nf = 0;
+        for (int p = p0; p < p1; p++) {
+            const int e = phase2 ? (ci_cur[p] >= 0) : (cc_cur[p] > 1);
             s_fl[p] = (unsigned char)e;
-            s_A[p] = e;
-            s_cc[4 * p] = 0; s_cc[4 * p + 1] = 0; s_cc[4 * p + 2] = 0; s_cc[4 * p + 3] = 0;
+            nf += e;
+            *reinterpret_cast<int4*>(&s_cc[4 * p]) = make_int4(0, 0, 0, 0);
         }
         if (tid == 0) s_var[7] = 0;
-        __syncthreads();
-        // b. processing order of the parents: index among the flagged nodes, list order (needs only the flags,
-        //    so it runs before the keys are visited and the two passes below share one barrier)
-        int norder = lds_excl_scan<NT>(s_A, size, s_tmp);
+        int m;
+        int fpos = block_excl_scan1<NT>(nf, s_tmpA, &m);
+        QT_STEP(0);
+        // b. processing order of the parents: list order while every multi-key node is split; the sweeps rank them below
+        for (int p = p0; p < p1; p++)
+            if (s_fl[p]) {
+                if (!phase2) {
+                    s_order[fpos] = (unsigned short)p;
+                } else {
+                    s_cand[fpos] = (unsigned short)p;
+                    // (size, creation index) as one key: creation indices are distinct and below 4 * 2048;
+                    // a level with 2^19 keys or more (sizes that do not fit) compares the two fields instead
+                    s_key[fpos] = packed_rank ? (((uint32_t)cc_cur[p] << 13) | (uint32_t)ci_cur[p]) : (uint32_t)cc_cur[p];
+                    s_B[fpos] = ci_cur[p];
+                }
+                fpos++;
+            }
         // c. child occupancy (DivideNode :431-476)
         //    A key first moves to its node's position in this step's list: s_childpos still holds the previous step's
         //    map (child position per quadrant of a split node, the new position in all four entries of any other node).
@@ -1730,21 +1851,10 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 nd = (uint32_t)(p | (qd << NB));
             }
         })
-        if (!phase2) {
-            for (int p = tid; p < size; p += NT)
-                if (s_fl[p]) s_order[s_A[p]] = (unsigned short)p;
-            __syncthreads();
-        } else {
-            const int m = norder;
-            for (int p = tid; p < size; p += NT)
-                if (s_fl[p]) {
-                    s_cand[s_A[p]] = (unsigned short)p;
-                    // (size, creation index) as one key: creation indices are distinct and below 4 * 2048;
-                    // a level with 2^19 keys or more (sizes that do not fit) compares the two fields instead
-                    s_key[s_A[p]] = packed_rank ? (((uint32_t)cc_cur[p] << 13) | (uint32_t)ci_cur[p]) : (uint32_t)cc_cur[p];
-                    s_B[s_A[p]] = ci_cur[p];
-                }
-            __syncthreads();
+        __syncthreads();
+        QT_STEP(1);
+        int norder = m;
+        if (phase2) {
             // rank in (size, creation) descending order: G lanes share one candidate's m comparisons
             int G = 1;
             while (G < 64 && m * (2 * G) <= NT) G *= 2;
@@ -1768,66 +1878,80 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 if (i < m && sub == 0) s_order[r] = s_cand[i];
             }
             __syncthreads();
-            // growth of |L| per split, in processing order; first index reaching N
-            for (int s = tid; s < m; s += NT) {
-                int p = s_order[s];
-                s_B[s] = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0) - 1;
-                s_C[s] = s_B[s];
+            // growth of |L| per split, in processing order; the splits up to and including the first that reaches N
+            const int cs = (m + NT - 1) / NT;
+            const int s0 = min(tid * cs, m), s1 = min(s0 + cs, m);
+            int gsum = 0;
+            for (int s_ = s0; s_ < s1; s_++) {
+                const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
+                gsum += (occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0) - 1;
             }
-            __syncthreads();
-            lds_excl_scan<NT>(s_C, m, s_tmp);
+            int gtot;
+            int gpos = block_excl_scan1<NT>(gsum, s_tmpB, &gtot);
             int below = 0;
-            for (int s = tid; s < m; s += NT) below += (size + s_C[s] + s_B[s] < N);
+            for (int s_ = s0; s_ < s1; s_++) {
+                const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
+                const int gr = (occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0) - 1;
+                below += (size + gpos + gr < N);
+                gpos += gr;
+            }
             if (below) atomicAdd(&s_var[7], below);
             __syncthreads();
             norder = min(s_var[7] + 1, m);
-            for (int p = tid; p < size; p += NT) s_fl[p] = 0;
+            for (int s_ = s0; s_ < s1; s_++) s_fl[s_order[s_]] = (unsigned char)(s_ < norder);
             __syncthreads();
-            for (int s = tid; s < norder; s += NT) s_fl[s_order[s]] = 1;
-            __syncthreads();
+            QT_STEP(2);
         }
-        // d. positions: children per parent (s_A low half), expandable children per parent (s_A high half), untouched nodes (s_C)
-        for (int s = tid; s < norder; s += NT) {
-            int p = s_order[s];
+        // d. positions: children and expandable children of the parents before this thread's, untouched nodes before its own
+        const int co = (norder + NT - 1) / NT;
+        const int o0 = min(tid * co, norder), o1 = min(o0 + co, norder);
+        int sum_par = 0, nu = 0;
+        for (int s_ = o0; s_ < o1; s_++) {
+            const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * (int)s_order[s_]]);
             // both counts in one word (each sum stays below 2^16: at most 4 * 2048), one scan for the two
-            s_A[s] = ((s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0)) |
-                     (((s_cc[4 * p] > 1) + (s_cc[4 * p + 1] > 1) + (s_cc[4 * p + 2] > 1) + (s_cc[4 * p + 3] > 1)) << 16);
+            sum_par += ((occ.x > 0) + (occ.y > 0) + (occ.z > 0) + (occ.w > 0)) |
+                       (((occ.x > 1) + (occ.y > 1) + (occ.z > 1) + (occ.w > 1)) << 16);
         }
-        for (int p = tid; p < size; p += NT) s_C[p] = !s_fl[p];
-        __syncthreads();
-        int both, nold;
-        lds_excl_scan2<NT>(s_A, norder, s_C, size, s_tmp, &both, &nold);
+        for (int p = p0; p < p1; p++) nu += !s_fl[p];
+        int par_pos, old_pos, both, nold;
+        block_excl_scan1_pair<NT>(sum_par, nu, phase2 ? s_tmpA : s_tmpB, &par_pos, &old_pos, &both, &nold);
+        QT_STEP(3);
         const int totalch = both & 0xffff, ncreated = both >> 16;
         const int newsize = totalch + nold;
         // e. build the next list
-        for (int s = tid; s < norder; s += NT) {
-            int p = s_order[s];
+        for (int s_ = o0; s_ < o1; s_++) {
+            const int p = s_order[s_];
+            const int4 occ = *reinterpret_cast<const int4*>(&s_cc[4 * p]);
+            const int oc[4] = {occ.x, occ.y, occ.z, occ.w};
             QNode q = rc[p];
             int hx = ceil_half(q.x1 - q.x0), hy = ceil_half(q.y1 - q.y0);
-            int nch = (s_cc[4 * p] > 0) + (s_cc[4 * p + 1] > 0) + (s_cc[4 * p + 2] > 0) + (s_cc[4 * p + 3] > 0);
-            int pos = totalch - ((s_A[s] & 0xffff) + nch);   // children of later parents come first
+            int nch = (oc[0] > 0) + (oc[1] > 0) + (oc[2] > 0) + (oc[3] > 0);
+            int pos = totalch - ((par_pos & 0xffff) + nch);   // children of later parents come first
+            int cpos[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int qd = 3; qd >= 0; qd--)
-                if (s_cc[4 * p + qd] > 0) {
+                if (oc[qd] > 0) {
                     QNode c;
                     c.x0 = (qd & 1) ? (short)(q.x0 + hx) : q.x0;
                     c.x1 = (qd & 1) ? q.x1 : (short)(q.x0 + hx);
                     c.y0 = (qd & 2) ? (short)(q.y0 + hy) : q.y0;
                     c.y1 = (qd & 2) ? q.y1 : (short)(q.y0 + hy);
                     rn[pos] = c;
-                    cn_nxt[pos] = s_cc[4 * p + qd];
+                    cn_nxt[pos] = oc[qd];
                     ci_nxt[pos] = -1;
                     s_childpos[4 * p + qd] = (unsigned short)pos;
+                    cpos[qd] = pos;
                     pos++;
                 }
-            int cb = s_A[s] >> 16;
+            int cb = par_pos >> 16;
 #pragma unroll
             for (int qd = 0; qd < 4; qd++)
-                if (s_cc[4 * p + qd] > 1) ci_nxt[s_childpos[4 * p + qd]] = (short)(cb++);
+                if (oc[qd] > 1) ci_nxt[cpos[qd]] = (short)(cb++);
+            par_pos += nch | (((oc[0] > 1) + (oc[1] > 1) + (oc[2] > 1) + (oc[3] > 1)) << 16);
         }
-        for (int p = tid; p < size; p += NT)
+        for (int p = p0; p < p1; p++)
             if (!s_fl[p]) {
-                int pos = totalch + s_C[p];
+                const int pos = totalch + old_pos++;
                 s_childpos[4 * p] = s_childpos[4 * p + 1] = s_childpos[4 * p + 2] = s_childpos[4 * p + 3] = (unsigned short)pos;
                 rn[pos] = rc[p];
                 cn_nxt[pos] = cc_cur[p];
@@ -1842,9 +1966,13 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         }
         cur ^= 1;
         __syncthreads();
+        QT_STEP(4);
+        QT_STEP_END();
         if (s_var[6]) break;
     }
 
+    QT_STEP_FLUSH();
+    QT_MARK(3);
     // ---- best key of every node (:689-710): largest response, first key on ties
     size = s_var[4];
     for (int p = tid; p < size; p += NT) s_best[p] = 0ull;
@@ -1862,6 +1990,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
         stage[p] = make_uint2(kxy[i], (uint32_t)(s_best[p] >> 32));
     }
     if (tid == 0) level_count[f * kMaxLevels + level] = min(size, L.kp_cap);
+    QT_MARK(4);
 }
 
 #define QUADTREE_PARAMS FrameGeom g, const uint32_t* __restrict__ cell_cand, const int* __restrict__ cell_count,          \

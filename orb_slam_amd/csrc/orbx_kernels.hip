@@ -1192,6 +1192,23 @@ __device__ __forceinline__ void lds_excl_scan2(int* a, int na, int* b, int nb, i
 // equal sizes by heap address, :633).
 // One workgroup per (level, frame).
 // ---------------------------------------------------------------------------
+// Number of keys among key[0..m) larger than ki, the share of lane `sub` of a group of G lanes: four keys per LDS read
+// (key is 16-byte aligned); the keys are distinct, so the ranks are a permutation.
+__device__ __forceinline__ int rank_packed(const uint32_t* key, int m, uint32_t ki, int sub, int G)
+{
+    int r = 0;
+    const int m4 = m >> 2;
+    const uint4* k4 = reinterpret_cast<const uint4*>(key);
+#pragma unroll 2
+    for (int j = sub; j < m4; j += G) {
+        const uint4 k = k4[j];
+        r += (k.x > ki) + (k.y > ki) + (k.z > ki) + (k.w > ki);
+    }
+    if (sub == 0)
+        for (int j = m4 << 2; j < m; j++) r += key[j] > ki;
+    return r;
+}
+
 struct QNode { short x0, x1, y0, y1; };
 // ctr[idx] += 1 from every calling lane.  Keys are listed cell by cell, so the lanes of a wavefront mostly sit in the
 // same node and quadrant, and LDS atomics on one address run one lane at a time: the lanes that share the first
@@ -1232,11 +1249,11 @@ __device__ __forceinline__ int ceil_half(int d)
 //
 // The rectangles of the tree do not depend on the data: a node is its root and the sequence of quadrants below it,
 // and DivideNode (:431-476) sends a key to the quadrant its coordinates select.  So a key's whole path is known in
-// advance, and the number of keys of any node is a sum over the leaves below it.  k_qt_bins (all keys of all
-// frames in parallel, no order) adds every key to its leaf at depth D and keeps the leaf's best key
-// (largest response, first in the reference's append order on ties); quadtree_counts_body (the prologue of the
-// quadtree kernels for such a level) builds the sums and maxima of the shallower depths and then runs the same
-// list steps as quadtree_body, reading a node's child occupancy from the sums instead of passing over the keys
+// advance, and the number of keys of any node is a sum over the leaves below it.  k_qt_bins (all frames and blocks of
+// leaves in parallel) counts every leaf's keys at depth D, keeps the leaf's best key (largest response, first in the
+// reference's append order on ties) and adds up the depths inside a block; quadtree_counts_body (the prologue of the
+// quadtree kernels for such a level) builds the sums and maxima of the few depths above the blocks and then runs the
+// same list steps as quadtree_body, reading a node's child occupancy from the sums instead of passing over the keys
 // (80 000 keys x 10 steps on one compute unit otherwise).  A node is (depth, path), path = root * 4^depth +
 // quadrant digits.  If a step has to split a node at depth D, the workgroup goes on with the passes over the keys.
 // ---------------------------------------------------------------------------
@@ -1251,53 +1268,15 @@ __host__ __device__ inline int qt_depth_off(int nIni, int d)
 __host__ __device__ inline size_t qt_counts_bytes(int nIni, int D) { return ((size_t)qt_depth_off(nIni, D + 1) * 12 + 255) & ~(size_t)255; }
 __host__ __device__ inline size_t qt_counts_best_off(int nIni, int D) { return ((size_t)qt_depth_off(nIni, D + 1) * 4 + 7) & ~(size_t)7; }
 
-__global__ __launch_bounds__(256) void k_qt_bins(FrameGeom g, CountLevels cl, const uint32_t* __restrict__ cell_cand,
-                                                 const int* __restrict__ cell_count, unsigned char* __restrict__ scratch)
-{
-    const int level = cl.level[blockIdx.y], f = blockIdx.z;
-    const LevelGeom& L = g.lv[level];
-    const int ncell = L.nCols * L.nRows;
-    const int c = blockIdx.x * 32 + (int)(threadIdx.x >> 3), sub = (int)(threadIdx.x & 7);      // 8 lanes per cell
-    if (c >= ncell) return;
-    const int cnt = cell_count[(size_t)f * g.ncells + L.cell_base + c];
-    if (sub >= cnt) return;
-    const int nIni = L.nIni, D = cl.depth[blockIdx.y];
-    unsigned char* slice = scratch + ((size_t)f * cl.n + blockIdx.y) * cl.stride;
-    int* H = reinterpret_cast<int*>(slice) + qt_depth_off(nIni, D);
-    unsigned long long* B = reinterpret_cast<unsigned long long*>(slice + qt_counts_best_off(nIni, D)) + qt_depth_off(nIni, D);
-    const uint32_t slot0 = (uint32_t)__mul24(c, L.cell_cap);
-    const uint32_t* src = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base + slot0;
-    const int ci = L.nCols > 1 ? (int)__umulhi((uint32_t)c, L.rcp_ncols) : c, cj = c - __mul24(ci, L.nCols);
-    const int xc = __mul24(cj, L.wCell) + 3, yc = __mul24(ci, L.hCell) + 3;
-    const float hX = L.hX;
-    for (int j = sub; j < cnt; j += 8) {
-        const uint32_t u = src[j];
-        const int x = xc + (int)((u >> 8) & 0xff), y = yc + (int)(u >> 16);
-        int r = (int)__fdiv_rn((float)x, hX);                      // :515-519
-        r = min(max(r, 0), nIni - 1);
-        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.height;
-        int path = r;
-        for (int d = 0; d < D; d++) {
-            const int hx = ceil_half(x1 - x0), hy = ceil_half(y1 - y0);
-            const int right = x < x0 + hx ? 0 : 1, low = y < y0 + hy ? 0 : 1;
-            if (right) x0 = (short)(x0 + hx); else x1 = (short)(x0 + hx);
-            if (low) y0 = (short)(y0 + hy); else y1 = (short)(y0 + hy);
-            path = path * 4 + right + 2 * low;
-        }
-        atomicAdd(&H[path], 1);
-        atomicMax(&B[path], ((unsigned long long)(u & 0xff) << 32) | (unsigned long long)(0xFFFFFFFFu - (slot0 + (uint32_t)j)));
-    }
-}
+// depth of the nodes one workgroup of k_qt_bins fills with everything below them: 5 depths (32 x 32 leaves) per workgroup
+constexpr int kQtBlockDepths = 5;
+__host__ __device__ inline int qt_block_depth(int D) { return D > kQtBlockDepths ? D - kQtBlockDepths : 0; }
 
-// LDS of quadtree_counts_body for M nodes (less than the node arrays of the key passes, whose allocation it uses)
-__host__ __device__ inline size_t qt_counts_lds(int M_)
-{
-    const size_t M = (size_t)M_;
-    return 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 96 * 4 + 2 * M * 4 + 2 * M * 2 + 2 * M * 2 + 2 * M + M + 64;
-}
-
-// Returns true when the level is done; false (nothing written) when a node at the leaves' depth would have to be
-// split, and the caller then runs the passes over the keys.  Uniform over the workgroup.  smem: qt_counts_lds(M) bytes.
+// One workgroup per node at depth Db = qt_block_depth(D) ("block"): it visits the FAST cells that can hold keys of the
+// block (the block's rectangle widened by a cell: a key's root comes from a float division, :515-519, so membership is
+// decided by the key's path, not by the rectangle), counts the block's keys per leaf and keeps every leaf's best key
+// with LDS atomics, adds the depths between the block and its leaves, and writes all of them with plain stores: no
+// global atomics and nothing to clear beforehand.  The depths above the blocks are summed by the level's workgroup.
 #ifdef ORBX_QT_TIMING
 // diagnostic build only: wall-clock marks (100 MHz) of every (frame, level) workgroup of the quadtree kernels
 __device__ unsigned long long g_qt_timing[64 * 8 * 8];
@@ -1311,7 +1290,11 @@ __device__ unsigned long long g_qt_step[64 * 8 * 8];     // time per stretch of 
                                                      g_qt_timing[((blockIdx.x & 63) * 8 + (blockIdx.y & 7)) * 8 + 7] = (unsigned long long)qt_steps_; } } while (0)
 extern "C" int orbx_debug_qt_timing(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_timing), sizeof(g_qt_timing)); }
 extern "C" int orbx_debug_qt_steps(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_step), sizeof(g_qt_step)); }
+__device__ unsigned long long g_qt_bins_t[2048 * 8];
+#define QTB_MARK(k) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z < 8) g_qt_bins_t[((blockIdx.z * 128 + blockIdx.x) & 2047) * 8 + (k)] = wall_clock64(); } while (0)
+extern "C" int orbx_debug_qt_bins(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qt_bins_t), sizeof(g_qt_bins_t)); }
 #else
+#define QTB_MARK(k)
 #define QT_MARK(sec)
 #define QT_NOTE(sec, v)
 #define QT_STEP_DECL
@@ -1320,8 +1303,158 @@ extern "C" int orbx_debug_qt_steps(unsigned long long* out) { return (int)hipMem
 #define QT_STEP_FLUSH()
 #endif
 
+// Candidates per (frame, level) of the levels that may run on node counts: the sum both the blocks of k_qt_bins and the
+// level's quadtree workgroup decide on (once here instead of once per block)
+__global__ __launch_bounds__(1024) void k_qt_totals(FrameGeom g, CountLevels cl, const int* __restrict__ cell_count,
+                                                    int* __restrict__ level_ncand)
+{
+    __shared__ int s_red[16];
+    const int level = cl.level[blockIdx.x], f = blockIdx.y, tid = threadIdx.x;
+    const LevelGeom& L = g.lv[level];
+    const int* counts = cell_count + (size_t)f * g.ncells + L.cell_base;
+    const int ncells = L.nCols * L.nRows;
+    int part = 0;
+    for (int c0 = tid; c0 < ncells; c0 += 1024 * 4) {
+        int v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = c0 + 1024 * q < ncells ? counts[c0 + 1024 * q] : 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) part += v[q];
+    }
+    part = wave_incl_scan(part);
+    if ((tid & 63) == 63) s_red[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int total = 0;
+        for (int w = 0; w < 16; w++) total += s_red[w];
+        level_ncand[f * kMaxLevels + level] = total;
+    }
+}
+
+constexpr int kQtBinsThreads = 256;
+__global__ __launch_bounds__(kQtBinsThreads) void k_qt_bins(FrameGeom g, CountLevels cl, const uint32_t* __restrict__ cell_cand,
+                                                 const int* __restrict__ cell_count, const int* __restrict__ level_ncand,
+                                                 unsigned char* __restrict__ scratch)
+{
+    constexpr int kNodes = 1 + 4 + 16 + 64 + 256 + 1024;      // nodes of a block over its kQtBlockDepths + 1 depths
+    __shared__ int s_H[kNodes];
+    __shared__ unsigned long long s_Bk[kNodes];
+    const int level = cl.level[blockIdx.y], f = blockIdx.z, tid = threadIdx.x;
+    const LevelGeom& L = g.lv[level];
+    const int nIni = L.nIni, D = cl.depth[blockIdx.y], Db = qt_block_depth(D), LB = D - Db;
+    const int pb = blockIdx.x;                          // path of the block: root * 4^Db + quadrant digits
+    if (pb >= (nIni << (2 * Db))) return;
+    QTB_MARK(0);
+    const int* counts = cell_count + (size_t)f * g.ncells + L.cell_base;
+    // the level runs on node counts only with min_ratio x nfeat candidates (the test its quadtree workgroup makes too)
+    if (level_ncand[f * kMaxLevels + level] < cl.min_ratio * L.nfeat) return;
+    const float hX = L.hX;
+    // the block's rectangle
+    const int root = pb >> (2 * Db);
+    int bx0 = (short)(int)__fmul_rn(hX, (float)root), bx1 = (short)(int)__fmul_rn(hX, (float)(root + 1)), by0 = 0, by1 = (short)L.height;
+    for (int d = 0; d < Db; d++) {
+        const int dig = (pb >> (2 * (Db - 1 - d))) & 3;
+        const int hx = ceil_half(bx1 - bx0), hy = ceil_half(by1 - by0);
+        if (dig & 1) bx0 = (short)(bx0 + hx); else bx1 = (short)(bx0 + hx);
+        if (dig & 2) by0 = (short)(by0 + hy); else by1 = (short)(by0 + hy);
+    }
+    for (int i = tid; i < kNodes; i += kQtBinsThreads) { s_H[i] = 0; s_Bk[i] = 0ull; }
+    __syncthreads();
+    QTB_MARK(1);
+    // cells whose keys (x in [cj * wCell + 3, cj * wCell + 3 + wCell), likewise y) can lie in the rectangle widened by a pixel
+    const int cj0 = max(0, (bx0 - 4) / L.wCell), cj1 = min(L.nCols - 1, max(bx1 - 3, 0) / L.wCell);
+    const int ci0 = max(0, (by0 - 4) / L.hCell), ci1 = min(L.nRows - 1, max(by1 - 3, 0) / L.hCell);
+    const int ncj = cj1 - cj0 + 1, nci = ci1 - ci0 + 1;
+    const int leaf_base = ((1 << (2 * LB)) - 1) / 3;     // first leaf entry of the block's arrays
+    const int sub = tid & 7;
+    const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
+    auto add_key = [&](uint32_t u, int xc, int yc, uint32_t slot) {
+        const int x = xc + (int)((u >> 8) & 0xff), y = yc + (int)(u >> 16);
+        int r = (int)__fdiv_rn((float)x, hX);                      // :515-519
+        r = min(max(r, 0), nIni - 1);
+        int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.height;
+        int path = r;
+        for (int d = 0; d < D; d++) {
+            const int hx = ceil_half(x1 - x0), hy = ceil_half(y1 - y0);
+            const int right = x < x0 + hx ? 0 : 1, low = y < y0 + hy ? 0 : 1;
+            if (right) x0 = (short)(x0 + hx); else x1 = (short)(x0 + hx);
+            if (low) y0 = (short)(y0 + hy); else y1 = (short)(y0 + hy);
+            path = path * 4 + right + 2 * low;
+        }
+        if ((path >> (2 * LB)) != pb) return;
+        const int leaf = leaf_base + (path & ((1 << (2 * LB)) - 1));
+        atomicAdd(&s_H[leaf], 1);
+        atomicMax(&s_Bk[leaf], ((unsigned long long)(u & 0xff) << 32) | (unsigned long long)(0xFFFFFFFFu - slot));
+    };
+    // 8 lanes per cell, four cells of a lane group in flight: their counts are loaded together, then their first two keys
+    // per lane (a cell rarely holds more than 16), so a workgroup waits for memory twice per 512 cells
+    const int ncr = (ncj > 0 && nci > 0) ? ncj * nci : 0;
+    for (int k0 = tid >> 3; k0 < ncr; k0 += kQtBinsThreads / 2) {
+        int cnt[4], xc[4], yc[4];
+        uint32_t slot0[4], u0[4], u1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int k = k0 + (kQtBinsThreads / 8) * q;
+            const int kk = k < ncr ? k : k0;
+            const int ci = ci0 + kk / ncj, cj = cj0 + kk % ncj;
+            const int c = __mul24(ci, L.nCols) + cj;
+            slot0[q] = (uint32_t)__mul24(c, L.cell_cap);
+            xc[q] = __mul24(cj, L.wCell) + 3;
+            yc[q] = __mul24(ci, L.hCell) + 3;
+            cnt[q] = k < ncr ? counts[c] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u0[q] = sub < cnt[q] ? cands[slot0[q] + sub] : 0u;
+            u1[q] = sub + 8 < cnt[q] ? cands[slot0[q] + sub + 8] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (sub < cnt[q]) add_key(u0[q], xc[q], yc[q], slot0[q] + (uint32_t)sub);
+            if (sub + 8 < cnt[q]) add_key(u1[q], xc[q], yc[q], slot0[q] + (uint32_t)sub + 8u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            for (int j = sub + 16; j < cnt[q]; j += 8) add_key(cands[slot0[q] + j], xc[q], yc[q], slot0[q] + (uint32_t)j);
+    }
+    __syncthreads();
+    QTB_MARK(2);
+    // the depths between the leaves and the block
+    for (int k = LB - 1; k >= 0; k--) {
+        const int o = ((1 << (2 * k)) - 1) / 3, oc = ((1 << (2 * (k + 1))) - 1) / 3, nk = 1 << (2 * k);
+        for (int i = tid; i < nk; i += kQtBinsThreads) {
+            s_H[o + i] = s_H[oc + 4 * i] + s_H[oc + 4 * i + 1] + s_H[oc + 4 * i + 2] + s_H[oc + 4 * i + 3];
+            s_Bk[o + i] = max(max(s_Bk[oc + 4 * i], s_Bk[oc + 4 * i + 1]), max(s_Bk[oc + 4 * i + 2], s_Bk[oc + 4 * i + 3]));
+        }
+        __syncthreads();
+    }
+    QTB_MARK(3);
+    unsigned char* slice = scratch + ((size_t)f * cl.n + blockIdx.y) * cl.stride;
+    int* H = reinterpret_cast<int*>(slice);
+    unsigned long long* B = reinterpret_cast<unsigned long long*>(slice + qt_counts_best_off(nIni, D));
+    for (int k = 0; k <= LB; k++) {
+        const int o = ((1 << (2 * k)) - 1) / 3, nk = 1 << (2 * k);
+        const int go = qt_depth_off(nIni, Db + k) + pb * nk;
+        for (int i = tid; i < nk; i += kQtBinsThreads) {
+            H[go + i] = s_H[o + i];
+            B[go + i] = s_Bk[o + i];
+        }
+    }
+    QTB_MARK(4);
+}
+
+// LDS of quadtree_counts_body for M nodes (less than the node arrays of the key passes, whose allocation it uses)
+__host__ __device__ inline size_t qt_counts_lds(int M_)
+{
+    const size_t M = (size_t)M_;
+    return 4 * M * 4 + 2 * M * 4 + 3 * M * 4 + 96 * 4 + 2 * M * 4 + 2 * M * 2 + 2 * M * 2 + 2 * M + M + 64;
+}
+
+// Returns true when the level is done; false (nothing written) when a node at the leaves' depth would have to be
+// split, and the caller then runs the passes over the keys.  Uniform over the workgroup.  smem: qt_counts_lds(M) bytes.
+
 template <int NT>
-__device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const CountLevels& cl, int slot, int level, int f,
+__device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const CountLevels& cl, int slot, int level, int f, int total,
                                                      const uint32_t* __restrict__ cell_cand, uint2* __restrict__ kp_stage,
                                                      int* __restrict__ level_count, int* __restrict__ level_ncand,
                                                      unsigned char* __restrict__ scratch, unsigned char* smem)
@@ -1348,8 +1481,8 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
     unsigned char* slice = scratch + ((size_t)f * cl.n + slot) * cl.stride;
     int* H = reinterpret_cast<int*>(slice);
     unsigned long long* B = reinterpret_cast<unsigned long long*>(slice + qt_counts_best_off(nIni, D));
-    // sums and maxima of the shallower depths
-    for (int d = D - 1; d >= 0; d--) {
+    // sums and maxima of the depths above the blocks k_qt_bins filled
+    for (int d = qt_block_depth(D) - 1; d >= 0; d--) {
         const int o = qt_depth_off(nIni, d), oc = qt_depth_off(nIni, d + 1), nd_ = nIni << (2 * d);
         for (int p = tid; p < nd_; p += NT) {
             const int4 h = *reinterpret_cast<const int4*>(H + oc + 4 * p);
@@ -1385,6 +1518,7 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
     // the child occupancy read from the sums
     int* const s_tmpA = s_var + 16;     // scan scratch, two arrays used in turn (32 ints each)
     int* const s_tmpB = s_var + 48;
+    const bool packed_rank = total < (1 << 19);
     QT_STEP_DECL;
     while (true) {
         size = s_var[4];
@@ -1427,7 +1561,8 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
                     s_order[fpos] = (unsigned short)p;
                 } else {
                     s_cand[fpos] = (unsigned short)p;
-                    s_key[fpos] = (uint32_t)cc_cur[p];
+                    // (size, creation index) as one key when the sizes fit beside the 13 bits of a creation index
+                    s_key[fpos] = packed_rank ? (((uint32_t)cc_cur[p] << 13) | (uint32_t)ci_cur[p]) : (uint32_t)cc_cur[p];
                     s_B[fpos] = ci_cur[p];
                 }
                 fpos++;
@@ -1444,10 +1579,14 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
                 int r = 0;
                 if (i < m) {
                     const uint32_t ki = s_key[i];
-                    const int ci = s_B[i];
-                    for (int j = sub; j < m; j += G) {
-                        const uint32_t kj = s_key[j];
-                        r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                    if (packed_rank) {
+                        r = rank_packed(s_key, m, ki, sub, G);
+                    } else {
+                        const int ci = s_B[i];
+                        for (int j = sub; j < m; j += G) {
+                            const uint32_t kj = s_key[j];
+                            r += (kj > ki) || (kj == ki && s_B[j] > ci);
+                        }
                     }
                 }
                 for (int d = 1; d < G; d <<= 1) r += __shfl_xor(r, d, 64);
@@ -1586,16 +1725,11 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
     // leaves): its tree stays shallow.  The passes over the keys below serve it only if the tree grows deeper than the
     // leaves after all; a level that keeps most of its candidates splits down to single keys and goes there directly.
     if (NB == 11 && cl.n > 0 && cl.slot[level] >= 0) {
-        const int* cnts = cell_count + (size_t)f * g.ncells + L.cell_base;
-        const int ncells = L.nCols * L.nRows;
-        int part = 0, total;
-        for (int c = tid; c < ncells; c += NT) part += cnts[c];
-        (void)block_excl_scan<NT>(part, reinterpret_cast<int*>(smem_lds), &total);
-        __syncthreads();
+        const int total = level_ncand[f * kMaxLevels + level];      // k_qt_totals has written it
         QT_MARK(1);
         QT_NOTE(6, total);
         if (total >= cl.min_ratio * L.nfeat &&
-            quadtree_counts_body<NT>(g, cl, cl.slot[level], level, f, cell_cand, kp_stage, level_count, level_ncand, count_scratch, smem_lds))
+            quadtree_counts_body<NT>(g, cl, cl.slot[level], level, f, total, cell_cand, kp_stage, level_count, level_ncand, count_scratch, smem_lds))
             return;
     }
     const int M = g.max_nodes;
@@ -1864,8 +1998,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 if (i < m) {
                     const uint32_t ki = s_key[i];
                     if (packed_rank) {
-#pragma unroll 4
-                        for (int j = sub; j < m; j += G) r += s_key[j] > ki;
+                        r = rank_packed(s_key, m, ki, sub, G);
                     } else {
                         const int ci = s_B[i];
                         for (int j = sub; j < m; j += G) {
@@ -2413,10 +2546,11 @@ void quadtree_count_levels(const FrameGeom& g, CountLevels& cl)
         while (D < 8 && (L.nIni << (2 * (D + 1))) <= leaf_bins) D++;
         if (D < 3) continue;
         cl.level[cl.n] = l;
-        cl.min_ratio = getenv("ORBX_QT_COUNT_RATIO") ? atoi(getenv("ORBX_QT_COUNT_RATIO")) : 8;
+        cl.min_ratio = getenv("ORBX_QT_COUNT_RATIO") ? atoi(getenv("ORBX_QT_COUNT_RATIO")) : 4;
         cl.slot[l] = cl.n;
         cl.depth[cl.n] = D;
         cl.max_cells = std::max(cl.max_cells, L.nCols * L.nRows);
+        cl.max_blocks = std::max(cl.max_blocks, L.nIni << (2 * qt_block_depth(D)));
         cl.stride = std::max(cl.stride, qt_counts_bytes(L.nIni, D));
         cl.n++;
     }
@@ -2432,11 +2566,11 @@ void launch_quadtree(const FrameGeom& g, const uint32_t* cell_cand, const int* c
     CountLevels cl{};
     for (int l = 0; l < kMaxLevels; l++) cl.slot[l] = -1;
     if (cl_in && cl_in->n > 0 && count_scratch && g.max_nodes <= kMaxNodes) {
-        // the leaves of the levels that run on node counts: cleared, then filled by all keys in parallel
+        // the node counts of the levels that run on them: every block of leaves by a workgroup of its own
         cl = *cl_in;
-        (void)hipMemsetAsync(count_scratch, 0, (size_t)nframes * cl.n * cl.stride, s);
-        hipLaunchKernelGGL(k_qt_bins, dim3((cl.max_cells + 31) / 32, cl.n, nframes), dim3(256), 0, s, g, cl, cell_cand,
-                           cell_count, count_scratch);
+        hipLaunchKernelGGL(k_qt_totals, dim3(cl.n, nframes), dim3(1024), 0, s, g, cl, cell_count, level_ncand);
+        hipLaunchKernelGGL(k_qt_bins, dim3(cl.max_blocks, cl.n, nframes), dim3(kQtBinsThreads), 0, s, g, cl, cell_cand,
+                           cell_count, level_ncand, count_scratch);
     }
     if (g.max_nodes > kMaxNodes) {      // node arrays (and the cell offsets behind them) in global memory
         hipLaunchKernelGGL(k_quadtree_big, grid, dim3(1024), 0, s, g, cell_cand, cell_count, cell_off, key_xy, key_resp,

@@ -31,6 +31,7 @@ struct CountLevels {
     int slot[kMaxLevels];       // level -> its place in level[] / depth[], -1 for the other levels
     int depth[kMaxLevels];      // depth of the leaves
     int max_cells;              // most FAST cells on one of them
+    int max_blocks;             // most leaf blocks (workgroups of k_qt_bins) on one of them
     int min_ratio;              // a level takes this form only with at least min_ratio x nfeat candidates
     size_t stride;              // bytes of scratch per (frame, listed level)
 };

@@ -45,6 +45,7 @@ def main():
             print("%5d %5d  %-5s %6d  %5d  %6.1f %6.1f  %6.1f  %6.1f  %6.1f  %6.1f" % (
                 f, lv, "keys" if m[5] else "count", m[6], m[7], (m[0] - t0) / 100.0, us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(0, 4)))
     print("launch span: %.1f us" % ((t[:, :, 4].max() - t0) / 100.0))
+    bins(lib, B)
     st = np.zeros(64 * 8 * 8, np.uint64)
     if hasattr(lib, "orbx_debug_qt_steps") and lib.orbx_debug_qt_steps(C.c_void_p(st.ctypes.data)) == 0:
         st = st.reshape(64, 8, 8)[:B].astype(np.int64)
@@ -52,6 +53,24 @@ def main():
         for lv in range(8):
             print("  level %d: " % lv + "  ".join("%6.1f" % (st[0, lv, k] / 100.0) for k in range(5)) +
                   "   shader clock %.0f MHz" % (st[0, lv, 6] / max(1, st[0, lv, 7]) * 100.0))
+
+
+def bins(lib, B):
+    if not hasattr(lib, "orbx_debug_qt_bins"):
+        return
+    t = np.zeros(2048 * 8, np.uint64)
+    if lib.orbx_debug_qt_bins(C.c_void_p(t.ctypes.data)) != 0:
+        return
+    t = t.reshape(2048, 8).astype(np.int64)
+    t = t[t[:, 0] > 0]
+    if not len(t):
+        return
+    t0 = t[:, 0].min()
+    print("k_qt_bins, blocks of the first listed level (%d workgroups): start after the first | zero | keys | sums | stores (us)" % len(t))
+    for row in t[np.argsort(t[:, 0])][:: max(1, len(t) // 12)]:
+        print("   %6.1f | %5.1f %5.1f %5.1f %5.1f" % ((row[0] - t0) / 100.0, (row[1] - row[0]) / 100.0, (row[2] - row[1]) / 100.0,
+                                                  (row[3] - row[2]) / 100.0, (row[4] - row[3]) / 100.0))
+    print("   span %.1f us" % ((t[:, 4].max() - t0) / 100.0))
 
 
 if __name__ == "__main__":

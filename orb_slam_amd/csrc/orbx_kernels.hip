@@ -59,15 +59,19 @@ __device__ __forceinline__ int reflect101(int p, int len)
 // ---------------------------------------------------------------------------
 // One thread = 16 plane bytes (pitch is a multiple of 64, planes are 64-byte aligned).  Pieces
 // that lie inside the image come in as four dwords when the source is dword-addressable
-// (aligned != 0); pieces touching the left/right border are gathered byte by byte.  The index
-// space lists all interior pieces first and the border pieces after them, so that (all but one)
-// wavefronts run only one of the two paths.
+// (aligned != 0), else (a width like 1241: every row starts at another byte of a dword) as the five
+// aligned dwords around them, shifted into place -- a misaligned dword load is split into several
+// cache accesses, and a byte gather is sixteen loads; pieces touching the left/right border are
+// gathered byte by byte.  The index space lists all interior pieces first and the border pieces
+// after them, so that (all but one) wavefronts run only one of the two paths.
+// [lo, hi): the bytes of the whole batch, which an aligned load around a piece must not leave.
 __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ in, int stride, size_t frame_stride,
-                                                    uint8_t* __restrict__ pyr, FrameGeom g, int aligned)
+                                                    uint8_t* __restrict__ pyr, FrameGeom g, int aligned,
+                                                    const uint8_t* lo, const uint8_t* hi)
 {
     const LevelGeom& L = g.lv[0];
     const int per_row = L.pitch >> 4;
-    const int n_int = aligned ? (L.w >> 4) : 0, n_brd = per_row - n_int;
+    const int n_int = L.w >> 4, n_brd = per_row - n_int;
     const int n_interior = n_int * L.rows;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= per_row * L.rows) return;
@@ -86,10 +90,18 @@ __global__ __launch_bounds__(256) void k_pyr_level0(const uint8_t* __restrict__ 
     const uint8_t* src = in + (size_t)blockIdx.y * frame_stride + (size_t)sy * stride;
     const int sx0 = (piece << 4) - kPadX;
     uint32_t v[4];
-    if (interior) {
-        const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + sx0);
+    const uint8_t* p = src + sx0;
+    const unsigned a = aligned ? 0u : (unsigned)(reinterpret_cast<uintptr_t>(p) & 3u);
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(p - a);
+    if (interior && a == 0) {
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = s4[j];
+    } else if (interior && reinterpret_cast<const uint8_t*>(s4) >= lo && reinterpret_cast<const uint8_t*>(s4 + 5) <= hi) {
+        uint32_t w[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) w[j] = s4[j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = __builtin_amdgcn_alignbyte(w[j + 1], w[j], a);
     } else {
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -2429,7 +2441,11 @@ void launch_pyr_level0(const uint8_t* in, int stride, size_t frame_stride, uint8
     const LevelGeom& L = g.lv[0];
     const int aligned = (((uintptr_t)in | (uintptr_t)frame_stride | (uintptr_t)stride) & 3u) == 0;
     dim3 grid(((L.pitch >> 4) * L.rows + 255) / 256, nframes);
-    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, in, stride, frame_stride, pyr, g, aligned);
+    // the bytes the batch covers, rounded inwards to whole dwords
+    const uintptr_t b0 = (uintptr_t)in, b1 = b0 + (size_t)(nframes - 1) * frame_stride + (size_t)(L.h - 1) * stride + L.w;
+    const uint8_t* lo = reinterpret_cast<const uint8_t*>((b0 + 3) & ~(uintptr_t)3);
+    const uint8_t* hi = reinterpret_cast<const uint8_t*>(b1 & ~(uintptr_t)3);
+    hipLaunchKernelGGL(k_pyr_level0, grid, dim3(256), 0, s, in, stride, frame_stride, pyr, g, aligned, lo, hi);
 }
 
 void launch_pyr_resize(uint8_t* pyr, const FrameGeom& g, int level, const XTab* xtab, const YTab* ytab,

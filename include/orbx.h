@@ -374,6 +374,30 @@ int orbx_match_candidates(orbx_ctx *ctx, const orbx_keypoint *kps, const float *
                           int mp_index, int mp_observations,
                           int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *best_idx);
 
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:270-404 (the
+ * search of Tracking::TrackReferenceKeyFrame and Relocalization).  A DBoW2::FeatureVector (pKF->mFeatVec, F.mFeatVec) is
+ * passed as its node ids in ascending order (the order a std::map iterates in), nodes + 1 offsets and the feature
+ * indices of every node in stored order.  kf_kps = pKF->mvKeysUn, kf_has_point[i] = vpMapPointsKF[i] exists and is
+ * not bad (:304-308), f_kps = F.mvKeys (only the angles are read, :349).  matches_f[n_f]: the keypoint of the keyframe
+ * whose map point vpMapPointMatches[i] receives, -1 for NULL.  The device computes the distance of every (keyframe
+ * keypoint, frame keypoint) pair that shares a node; the walk that skips frame keypoints matched earlier (:320-321),
+ * the TH_LOW / ratio test (:339-341) and the rotation histogram (:347-357, :383-401) run on the host. */
+int orbx_search_by_bow_frame(orbx_ctx *ctx, const orbx_keypoint *kf_kps, const uint32_t *kf_desc,
+                             const uint8_t *kf_has_point, int n_kf,
+                             const int32_t *kf_node, const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes,
+                             const orbx_keypoint *f_kps, const uint32_t *f_desc, int n_f,
+                             const int32_t *f_node, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                             float nnratio, int check_orientation, int32_t *matches_f, int *nmatches);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:635-768 (loop
+ * closing): both sides need a good map point (:671-675, :689-693), a keypoint of pKF2 is taken once (vbMatched2), the
+ * distance must be strictly below TH_LOW (:711).  matches12[n1]: the keypoint of pKF2 whose map point vpMatches12[i]
+ * receives, -1 for NULL. */
+int orbx_search_by_bow_keyframes(orbx_ctx *ctx, const orbx_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1, int n1,
+                                 const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                 const orbx_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2, int n2,
+                                 const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                 float nnratio, int check_orientation, int32_t *matches12, int *nmatches);
+
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono, numVisibleMpt),
  * src/ORBmatcher.cc:1440-1593 -- the search of Tracking::TrackWithMotionModel -- from the point where the map points of
  * the last frame have been projected into the current one (:1496 on).  The projection (:1451-1493) stays with the

@@ -336,6 +336,18 @@ struct MatchCandidateTable {
     size_t size(size_t i) const { return (size_t)(cand_off[i + 1] - cand_off[i]); }
 };
 
+// A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned int>>) flattened in the map's order: node ids ascending,
+// node.size() + 1 offsets, the feature indices of every node as stored
+struct FeatureVector {
+    std::vector<int32_t> node, off{0}, idx;
+    void add(int32_t node_id, const std::vector<unsigned int>& features)     // call in ascending order of node_id
+    {
+        node.push_back(node_id);
+        idx.insert(idx.end(), features.begin(), features.end());
+        off.push_back((int32_t)idx.size());
+    }
+};
+
 // What ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) reads of each map point of
 // the last frame after projecting it (src/ORBmatcher.cc:1478-1510): visible = non-null, not an outlier, invzc >= 0
 // and (u, v) inside the image bounds; octave / angle = LastFrame.mvKeys[i]; parallel arrays of one length
@@ -473,6 +485,43 @@ public:
                                     std::vector<int32_t>& mvpMatchScore)
     {
         return MatchCandidates(keysUn, mvuRight, t, mp, i, th, frame_obs, frame_match, mvpMatchScore);
+    }
+
+    // SearchByBoW(pKF, F, vpMapPointMatches), src/ORBmatcher.cc:270-404.  kfHasPoint[i] = pKF's map point i exists and is
+    // not bad; vpMapPointMatches[i] = index of the keyframe keypoint whose map point the frame keypoint i receives, -1 = NULL.
+    int SearchByBoW(const std::vector<orbx_keypoint>& kfKeysUn, const uint8_t* kfDesc, const std::vector<uint8_t>& kfHasPoint,
+                    const FeatureVector& kfFeatVec, const std::vector<orbx_keypoint>& fKeys, const uint8_t* fDesc,
+                    const FeatureVector& fFeatVec, std::vector<int32_t>& vpMapPointMatches)
+    {
+        if (kfHasPoint.size() != kfKeysUn.size()) throw std::invalid_argument("array lengths do not agree");
+        vpMapPointMatches.assign(fKeys.size(), -1);
+        int nmatches = 0;
+        check(orbx_search_by_bow_frame(ex_.context(), kfKeysUn.data(), reinterpret_cast<const uint32_t*>(kfDesc), kfHasPoint.data(),
+                                       (int)kfKeysUn.size(), kfFeatVec.node.data(), kfFeatVec.off.data(), kfFeatVec.idx.data(),
+                                       (int)kfFeatVec.node.size(), fKeys.data(), reinterpret_cast<const uint32_t*>(fDesc),
+                                       (int)fKeys.size(), fFeatVec.node.data(), fFeatVec.off.data(), fFeatVec.idx.data(),
+                                       (int)fFeatVec.node.size(), mfNNratio, mbCheckOrientation ? 1 : 0,
+                                       vpMapPointMatches.data(), &nmatches));
+        return nmatches;
+    }
+
+    // SearchByBoW(pKF1, pKF2, vpMatches12), src/ORBmatcher.cc:635-768.  vpMatches12[i] = index of the keypoint of pKF2 whose
+    // map point keypoint i of pKF1 receives, -1 = NULL.
+    int SearchByBoW(const std::vector<orbx_keypoint>& keysUn1, const uint8_t* desc1, const std::vector<uint8_t>& hasPoint1,
+                    const FeatureVector& featVec1, const std::vector<orbx_keypoint>& keysUn2, const uint8_t* desc2,
+                    const std::vector<uint8_t>& hasPoint2, const FeatureVector& featVec2, std::vector<int32_t>& vpMatches12)
+    {
+        if (hasPoint1.size() != keysUn1.size() || hasPoint2.size() != keysUn2.size())
+            throw std::invalid_argument("array lengths do not agree");
+        vpMatches12.assign(keysUn1.size(), -1);
+        int nmatches = 0;
+        check(orbx_search_by_bow_keyframes(ex_.context(), keysUn1.data(), reinterpret_cast<const uint32_t*>(desc1), hasPoint1.data(),
+                                           (int)keysUn1.size(), featVec1.node.data(), featVec1.off.data(), featVec1.idx.data(),
+                                           (int)featVec1.node.size(), keysUn2.data(), reinterpret_cast<const uint32_t*>(desc2),
+                                           hasPoint2.data(), (int)keysUn2.size(), featVec2.node.data(), featVec2.off.data(),
+                                           featVec2.idx.data(), (int)featVec2.node.size(), mfNNratio, mbCheckOrientation ? 1 : 0,
+                                           vpMatches12.data(), &nmatches));
+        return nmatches;
     }
 
     // SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt), src/ORBmatcher.cc:1440-1593, from the

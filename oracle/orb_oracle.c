@@ -2128,3 +2128,139 @@ int oo_search_by_projection_budget(const oo_keypoint *kps, const uint32_t *desc,
     free(list);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------- *
+ * ORBmatcher::SearchByBoW.  A DBoW2::FeatureVector (std::map<NodeId, std::vector<unsigned>>) is passed as its
+ * node ids in ascending order (the map's iteration order), offsets and feature indices.
+ * ------------------------------------------------------------------------- */
+static int fv_lower_bound(const int32_t *node, int n, int from, int32_t key)
+{
+    int i = from;                                      /* lower_bound over the whole map = over the part not yet passed */
+    while (i < n && node[i] < key) i++;
+    return i;
+}
+
+static int rot_bin(float a1, float a2)
+{
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)roundf(rot * (1.0f / OO_HISTO_LENGTH));
+    if (bin == OO_HISTO_LENGTH) bin = 0;
+    return bin;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint*> &vpMapPointMatches), src/ORBmatcher.cc:270-404.
+ * kf_has_point[i]: vpMapPointsKF[i] exists and is not bad.  matches_f[n_f]: the keypoint of the keyframe whose map
+ * point vpMapPointMatches[i] holds, -1 for NULL.  Returns nmatches. */
+int oo_search_by_bow_frame(const oo_keypoint *kf_kps, const uint32_t *kf_desc, const uint8_t *kf_has_point,
+                           const int32_t *kf_node, const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes,
+                           const oo_keypoint *f_kps, const uint32_t *f_desc, int n_f,
+                           const int32_t *f_node, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                           float nnratio, int check_orientation, int32_t *matches_f)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n_f; i++) matches_f[i] = -1;                       /* :274 */
+    int *hist = (int *)calloc((size_t)OO_HISTO_LENGTH * (size_t)(n_f > 0 ? n_f : 1), sizeof(int));
+    int hn[OO_HISTO_LENGTH] = {0};
+    int KFit = 0, Fit = 0;
+    while (KFit != kf_nodes && Fit != f_nodes) {                           /* :291 */
+        if (kf_node[KFit] == f_node[Fit]) {
+            for (int iKF = kf_off[KFit]; iKF < kf_off[KFit + 1]; iKF++) {
+                const int realIdxKF = kf_idx[iKF];
+                if (!kf_has_point[realIdxKF]) continue;                    /* :304-308 */
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int iF = f_off[Fit]; iF < f_off[Fit + 1]; iF++) {
+                    const int realIdxF = f_idx[iF];
+                    if (matches_f[realIdxF] >= 0) continue;                /* :320-321 */
+                    const int dist = oo_hamming(kf_desc + 8 * (size_t)realIdxKF, f_desc + 8 * (size_t)realIdxF);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= OO_TH_LOW) {                              /* :339 */
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {   /* :341 */
+                        matches_f[bestIdxF] = realIdxKF;
+                        if (check_orientation) {                           /* :347-357 */
+                            const int bin = rot_bin(kf_kps[realIdxKF].angle, f_kps[bestIdxF].angle);
+                            hist[bin * n_f + hn[bin]++] = bestIdxF;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            KFit++; Fit++;
+        } else if (kf_node[KFit] < f_node[Fit]) {
+            KFit = fv_lower_bound(kf_node, kf_nodes, KFit, f_node[Fit]);   /* :375 */
+        } else {
+            Fit = fv_lower_bound(f_node, f_nodes, Fit, kf_node[KFit]);     /* :379 */
+        }
+    }
+    if (check_orientation) {                                               /* :383-401 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(hn, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { matches_f[hist[i * n_f + j]] = -1; nmatches--; }
+        }
+    }
+    free(hist);
+    return nmatches;
+}
+
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint*> &vpMatches12), src/ORBmatcher.cc:635-768.
+ * has_point1 / has_point2: the keypoint's map point exists and is not bad.  matches12[n1]: the keypoint of pKF2
+ * whose map point vpMatches12[i] holds, -1 for NULL.  Returns nmatches. */
+int oo_search_by_bow_keyframes(const oo_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1, int n1,
+                               const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                               const oo_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2, int n2,
+                               const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                               float nnratio, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                        /* :647 */
+    uint8_t *vbMatched2 = (uint8_t *)calloc((size_t)(n2 > 0 ? n2 : 1), 1); /* :648 */
+    int *hist = (int *)calloc((size_t)OO_HISTO_LENGTH * (size_t)(n1 > 0 ? n1 : 1), sizeof(int));
+    int hn[OO_HISTO_LENGTH] = {0};
+    int f1it = 0, f2it = 0;
+    while (f1it != nodes1 && f2it != nodes2) {                             /* :663 */
+        if (node1[f1it] == node2[f2it]) {
+            for (int i1 = off1[f1it]; i1 < off1[f1it + 1]; i1++) {
+                const int i1x = idx1[i1];
+                if (!has_point1[i1x]) continue;                            /* :671-675 */
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int i2 = off2[f2it]; i2 < off2[f2it + 1]; i2++) {
+                    const int i2x = idx2[i2];
+                    if (vbMatched2[i2x] || !has_point2[i2x]) continue;     /* :689-693 */
+                    const int dist = oo_hamming(d1 + 8 * (size_t)i1x, d2 + 8 * (size_t)i2x);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2x; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < OO_TH_LOW) {                               /* :711: strictly below here */
+                    if ((float)bestDist1 < nnratio * (float)bestDist2) {
+                        matches12[i1x] = bestIdx2;                         /* :715 */
+                        vbMatched2[bestIdx2] = 1;
+                        if (check_orientation) {
+                            const int bin = rot_bin(k1[i1x].angle, k2[bestIdx2].angle);
+                            hist[bin * n1 + hn[bin]++] = i1x;
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (node1[f1it] < node2[f2it]) {
+            f1it = fv_lower_bound(node1, nodes1, f1it, node2[f2it]);
+        } else {
+            f2it = fv_lower_bound(node2, nodes2, f2it, node1[f1it]);
+        }
+    }
+    if (check_orientation) {                                               /* :747-765 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(hn, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { matches12[hist[i * n1 + j]] = -1; nmatches--; }
+        }
+    }
+    free(vbMatched2); free(hist);
+    return nmatches;
+}

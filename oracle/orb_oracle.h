@@ -288,6 +288,21 @@ int oo_search_by_projection_budget(const oo_keypoint *kps, const uint32_t *desc,
                                    const int32_t *mp_observations, int M, float th, float nnratio, double time_constr,
                                    int32_t *frame_obs, int32_t *frame_match, int32_t *match_score, int *stopped_at);
 
+/* ORBmatcher::SearchByBoW: KeyFrame against Frame (src/ORBmatcher.cc:270-404) and KeyFrame against KeyFrame (:635-768).
+ * A DBoW2::FeatureVector is passed as node ids in ascending order, offsets (nodes + 1) and feature indices;
+ * has_point = the keypoint's map point exists and is not bad; the outputs hold keypoint indices of the other side
+ * (-1 = NULL).  Both return nmatches. */
+int oo_search_by_bow_frame(const oo_keypoint *kf_kps, const uint32_t *kf_desc, const uint8_t *kf_has_point,
+                           const int32_t *kf_node, const int32_t *kf_off, const int32_t *kf_idx, int kf_nodes,
+                           const oo_keypoint *f_kps, const uint32_t *f_desc, int n_f,
+                           const int32_t *f_node, const int32_t *f_off, const int32_t *f_idx, int f_nodes,
+                           float nnratio, int check_orientation, int32_t *matches_f);
+int oo_search_by_bow_keyframes(const oo_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1, int n1,
+                               const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                               const oo_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2, int n2,
+                               const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                               float nnratio, int check_orientation, int32_t *matches12);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

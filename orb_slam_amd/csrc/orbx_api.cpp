@@ -1986,6 +1986,120 @@ int orbx_match_candidates(orbx_ctx* c, const orbx_keypoint* kps, const float* u_
     return ORBX_OK;
 }
 
+// ORBmatcher::SearchByBoW, both forms (src/ORBmatcher.cc:270-404 and :635-768): the queries are the keypoints of side 1
+// that hold a good map point and lie in a vocabulary node both feature vectors have, a query's candidates are the
+// keypoints of side 2 in that node.  The device computes every (query, candidate) distance in one call; the walk over
+// the nodes, with what earlier queries matched taken out of the later ones' lists, runs on the host.
+static int search_by_bow(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d1, const uint8_t* has_point1, int n1,
+                         const int32_t* node1, const int32_t* off1, const int32_t* idx1, int nodes1,
+                         const orbx_keypoint* k2, const uint32_t* d2, const uint8_t* has_point2, int n2,
+                         const int32_t* node2, const int32_t* off2, const int32_t* idx2, int nodes2, float nnratio,
+                         int check_orientation, bool keyframes, int32_t* matches, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (n1 < 0 || n2 < 0 || nodes1 < 0 || nodes2 < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    const int nout = keyframes ? n1 : n2;
+    if (nout > 0 && !matches) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < nout; i++) matches[i] = -1;                           // :274, :647
+    if (n1 == 0 || n2 == 0 || nodes1 == 0 || nodes2 == 0) return ORBX_OK;
+    if (!k1 || !d1 || !has_point1 || !node1 || !off1 || !idx1 || !k2 || !d2 || !node2 || !off2 || !idx2 ||
+        (keyframes && !has_point2))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 1; i < nodes1; i++) if (node1[i] <= node1[i - 1]) return fail(c, ORBX_ERR_INVALID, "node ids must ascend");
+    for (int i = 1; i < nodes2; i++) if (node2[i] <= node2[i - 1]) return fail(c, ORBX_ERR_INVALID, "node ids must ascend");
+    for (int i = 0; i < off1[nodes1]; i++) if (idx1[i] < 0 || idx1[i] >= n1) return fail(c, ORBX_ERR_INVALID, "feature index outside side 1");
+    for (int i = 0; i < off2[nodes2]; i++) if (idx2[i] < 0 || idx2[i] >= n2) return fail(c, ORBX_ERR_INVALID, "feature index outside side 2");
+    constexpr int kHisto = 30, kThLow = 50;                                   // HISTO_LENGTH, TH_LOW
+    // the common nodes (the iterator walk of :291-381 is a merge of two ascending sequences) and the queries
+    struct Pair { int a, b; };
+    std::vector<Pair> common;
+    for (int a = 0, b = 0; a < nodes1 && b < nodes2;) {
+        if (node1[a] == node2[b]) common.push_back(Pair{a++, b++});
+        else if (node1[a] < node2[b]) a++;
+        else b++;
+    }
+    std::vector<int32_t> qi, qnode, coff(1, 0), cidx;
+    std::vector<uint32_t> qd;
+    for (const Pair& pr : common)
+        for (int i = off1[pr.a]; i < off1[pr.a + 1]; i++) {
+            const int i1 = idx1[i];
+            if (!has_point1[i1]) continue;                                    // :304-308, :671-675
+            qi.push_back(i1);
+            qnode.push_back(pr.b);
+            cidx.insert(cidx.end(), idx2 + off2[pr.b], idx2 + off2[pr.b + 1]);
+            coff.push_back((int32_t)cidx.size());
+            if (cidx.size() > 0x7fffffffu) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates");
+        }
+    const int Q = (int)qi.size();
+    if (Q == 0 || cidx.empty()) return ORBX_OK;
+    qd.resize((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) std::memcpy(&qd[(size_t)q * 8], d1 + (size_t)qi[q] * 8, 32);
+    std::vector<uint16_t> dist(cidx.size());
+    int rc = orbx_hamming_csr(c, qd.data(), Q, d2, n2, coff.data(), cidx.data(), dist.data());
+    if (rc != ORBX_OK) return rc;
+
+    int nm = 0;
+    std::vector<int32_t> rotHist[kHisto];
+    std::vector<uint8_t> taken(n2, 0);                                        // vpMapPointMatches[idx] != NULL / vbMatched2
+    for (int q = 0; q < Q; q++) {
+        const int i1 = qi[q];
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int k = coff[q]; k < coff[q + 1]; k++) {
+            const int i2 = cidx[k];
+            if (taken[i2]) continue;                                          // :320-321, :689
+            if (keyframes && !has_point2[i2]) continue;                       // :689-693
+            const int d = dist[k];
+            if (d < bestDist1) { bestDist2 = bestDist1; bestDist1 = d; bestIdx2 = i2; }
+            else if (d < bestDist2) bestDist2 = d;
+        }
+        const bool low = keyframes ? bestDist1 < kThLow : bestDist1 <= kThLow;   // :711 against :339
+        if (low && (float)bestDist1 < nnratio * (float)bestDist2) {           // :341, :713
+            taken[bestIdx2] = 1;
+            if (keyframes) matches[i1] = bestIdx2; else matches[bestIdx2] = i1;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / kHisto));
+                if (bin == kHisto) bin = 0;
+                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");   // the reference asserts
+                rotHist[bin].push_back(keyframes ? i1 : bestIdx2);
+            }
+            nm++;
+        }
+    }
+    if (check_orientation) {                                                  // :383-401, :747-765
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+        for (int i = 0; i < kHisto; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches[j] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+int orbx_search_by_bow_frame(orbx_ctx* c, const orbx_keypoint* kf_kps, const uint32_t* kf_desc, const uint8_t* kf_has_point,
+                             int n_kf, const int32_t* kf_node, const int32_t* kf_off, const int32_t* kf_idx, int kf_nodes,
+                             const orbx_keypoint* f_kps, const uint32_t* f_desc, int n_f, const int32_t* f_node,
+                             const int32_t* f_off, const int32_t* f_idx, int f_nodes, float nnratio, int check_orientation,
+                             int32_t* matches_f, int* nmatches)
+{
+    return search_by_bow(c, kf_kps, kf_desc, kf_has_point, n_kf, kf_node, kf_off, kf_idx, kf_nodes, f_kps, f_desc, nullptr, n_f,
+                         f_node, f_off, f_idx, f_nodes, nnratio, check_orientation, false, matches_f, nmatches);
+}
+
+int orbx_search_by_bow_keyframes(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d1, const uint8_t* has_point1, int n1,
+                                 const int32_t* node1, const int32_t* off1, const int32_t* idx1, int nodes1,
+                                 const orbx_keypoint* k2, const uint32_t* d2, const uint8_t* has_point2, int n2,
+                                 const int32_t* node2, const int32_t* off2, const int32_t* idx2, int nodes2, float nnratio,
+                                 int check_orientation, int32_t* matches12, int* nmatches)
+{
+    return search_by_bow(c, k1, d1, has_point1, n1, node1, off1, idx1, nodes1, k2, d2, has_point2, n2, node2, off2, idx2,
+                         nodes2, nnratio, check_orientation, true, matches12, nmatches);
+}
+
 int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
                                    float min_x, float min_y, float inv_w, float inv_h, const uint8_t* lp_visible,
                                    const float* lp_u, const float* lp_v, const float* lp_invzc, const int32_t* lp_octave,

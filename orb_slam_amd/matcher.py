@@ -314,6 +314,48 @@ class ORBmatcher:
             match_score.ctypes.data, C.byref(best)))
         return best.value
 
+    @staticmethod
+    def feature_vector(fv):
+        """A DBoW2::FeatureVector given as {node id: [feature indices]} -> (node ids ascending, offsets, indices)"""
+        nodes = np.array(sorted(fv), np.int32)
+        off = np.zeros(len(nodes) + 1, np.int32)
+        for k, n in enumerate(nodes):
+            off[k + 1] = off[k] + len(fv[int(n)])
+        idx = np.concatenate([np.asarray(fv[int(n)], np.int32) for n in nodes]) if len(nodes) else np.zeros(0, np.int32)
+        return nodes, off, np.ascontiguousarray(idx, np.int32)
+
+    def SearchByBoW(self, kf_keys, kf_desc, kf_has_point, kf_featvec, f_keys, f_desc, f_featvec):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (src/ORBmatcher.cc:270-404).  Feature vectors as
+        {node id: [feature indices]}; returns (nmatches, matches_f): the keyframe keypoint per frame keypoint or -1."""
+        k1, k2 = np.ascontiguousarray(kf_keys, KP_DTYPE), np.ascontiguousarray(f_keys, KP_DTYPE)
+        d1, d2 = _desc(kf_desc), _desc(f_desc)
+        hp = np.ascontiguousarray(kf_has_point, np.uint8)
+        n1, o1, i1 = self.feature_vector(kf_featvec)
+        n2, o2, i2 = self.feature_vector(f_featvec)
+        out = np.full(len(k2), -1, np.int32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_bow_frame(
+            self._ctx, k1.ctypes.data, d1.ctypes.data, hp.ctypes.data, len(k1), n1.ctypes.data, o1.ctypes.data, i1.ctypes.data,
+            len(n1), k2.ctypes.data, d2.ctypes.data, len(k2), n2.ctypes.data, o2.ctypes.data, i2.ctypes.data, len(n2),
+            self.mfNNratio, int(bool(self.mbCheckOrientation)), out.ctypes.data, C.byref(nm)))
+        return nm.value, out
+
+    def SearchByBoW_KeyFrames(self, keys1, desc1, has_point1, featvec1, keys2, desc2, has_point2, featvec2):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (src/ORBmatcher.cc:635-768); returns (nmatches,
+        matches12): the keypoint of the second keyframe per keypoint of the first or -1."""
+        k1, k2 = np.ascontiguousarray(keys1, KP_DTYPE), np.ascontiguousarray(keys2, KP_DTYPE)
+        d1, d2 = _desc(desc1), _desc(desc2)
+        h1, h2 = np.ascontiguousarray(has_point1, np.uint8), np.ascontiguousarray(has_point2, np.uint8)
+        n1, o1, i1 = self.feature_vector(featvec1)
+        n2, o2, i2 = self.feature_vector(featvec2)
+        out = np.full(len(k1), -1, np.int32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_bow_keyframes(
+            self._ctx, k1.ctypes.data, d1.ctypes.data, h1.ctypes.data, len(k1), n1.ctypes.data, o1.ctypes.data, i1.ctypes.data,
+            len(n1), k2.ctypes.data, d2.ctypes.data, h2.ctypes.data, len(k2), n2.ctypes.data, o2.ctypes.data, i2.ctypes.data,
+            len(n2), self.mfNNratio, int(bool(self.mbCheckOrientation)), out.ctypes.data, C.byref(nm)))
+        return nm.value, out
+
     def SearchByProjectionLast(self, keys, desc, mvuRight, grid, last, th, mbf, bForward, bBackward, frame_obs, frame_match):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) (src/ORBmatcher.cc:1440-1593)
         from :1496 on.  last: dict of per-keypoint arrays of the last frame (visible, u, v, invzc, octave, angle,

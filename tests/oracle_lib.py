@@ -118,6 +118,10 @@ class Oracle:
                                             _ci, _f, _f, _i32p, _i32p, _i32p]
         lib.oo_search_by_projection_one_point.argtypes = [C.c_void_p, _u32p, _f32p, _ci, _f32p, _f, _f, _f, _f, _ci, _ci, _f,
                                                           _f, _f, _ci, _f, _u32p, _ci, _ci, _f, _f, _i32p, _i32p, _i32p]
+        lib.oo_search_by_bow_frame.argtypes = [C.c_void_p, _u32p, _u8p, _i32p, _i32p, _i32p, _ci, C.c_void_p, _u32p, _ci, _i32p,
+                                               _i32p, _i32p, _ci, _f, _ci, _i32p]
+        lib.oo_search_by_bow_keyframes.argtypes = [C.c_void_p, _u32p, _u8p, _ci, _i32p, _i32p, _i32p, _ci, C.c_void_p, _u32p,
+                                                   _u8p, _ci, _i32p, _i32p, _i32p, _ci, _f, _ci, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -461,6 +465,46 @@ class Oracle:
             int(mp["mnTrackScaleLevel"][i]), float(mp["mTrackViewCos"][i]), _ptr(md.view(np.uint32), _u32p),
             int(mp["Observations"][i]), int(i), th, nnratio, _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p),
             _ptr(match_score, _i32p))
+
+    @staticmethod
+    def _fv(fv):
+        nodes = np.array(sorted(fv), np.int32)
+        off = np.zeros(len(nodes) + 1, np.int32)
+        for k, n in enumerate(nodes):
+            off[k + 1] = off[k] + len(fv[int(n)])
+        idx = np.concatenate([np.asarray(fv[int(n)], np.int32) for n in nodes]) if len(nodes) else np.zeros(1, np.int32)
+        return nodes if len(nodes) else np.zeros(1, np.int32), off, np.ascontiguousarray(idx, np.int32), len(nodes)
+
+    def search_by_bow_frame(self, kf_kps, kf_desc, kf_has_point, kf_fv, f_kps, f_desc, f_fv, nnratio, check_ori):
+        """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) -> (nmatches, matches_f)"""
+        k1, k2 = np.ascontiguousarray(kf_kps, KP_DTYPE), np.ascontiguousarray(f_kps, KP_DTYPE)
+        d1 = np.ascontiguousarray(kf_desc, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(f_desc, np.uint8).reshape(-1, 32)
+        hp = np.ascontiguousarray(kf_has_point, np.uint8)
+        n1, o1, i1, c1 = self._fv(kf_fv)
+        n2, o2, i2, c2 = self._fv(f_fv)
+        out = np.full(max(len(k2), 1), -1, np.int32)
+        nm = self.lib.oo_search_by_bow_frame(k1.ctypes.data, _ptr(d1.view(np.uint32), _u32p), _ptr(hp, _u8p), _ptr(n1, _i32p),
+                                             _ptr(o1, _i32p), _ptr(i1, _i32p), c1, k2.ctypes.data,
+                                             _ptr(d2.view(np.uint32), _u32p), len(k2), _ptr(n2, _i32p), _ptr(o2, _i32p),
+                                             _ptr(i2, _i32p), c2, nnratio, int(check_ori), _ptr(out, _i32p))
+        return nm, out[:len(k2)]
+
+    def search_by_bow_keyframes(self, k1, d1, h1, fv1, k2, d2, h2, fv2, nnratio, check_ori):
+        """ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) -> (nmatches, matches12)"""
+        k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        h1, h2 = np.ascontiguousarray(h1, np.uint8), np.ascontiguousarray(h2, np.uint8)
+        n1, o1, i1, c1 = self._fv(fv1)
+        n2, o2, i2, c2 = self._fv(fv2)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        nm = self.lib.oo_search_by_bow_keyframes(k1.ctypes.data, _ptr(d1.view(np.uint32), _u32p), _ptr(h1, _u8p), len(k1),
+                                                 _ptr(n1, _i32p), _ptr(o1, _i32p), _ptr(i1, _i32p), c1, k2.ctypes.data,
+                                                 _ptr(d2.view(np.uint32), _u32p), _ptr(h2, _u8p), len(k2), _ptr(n2, _i32p),
+                                                 _ptr(o2, _i32p), _ptr(i2, _i32p), c2, nnratio, int(check_ori),
+                                                 _ptr(out, _i32p))
+        return nm, out[:len(k1)]
 
     def search_by_projection_last(self, kps, desc, u_right, grid, last, th, mbf, forward, backward, check_ori,
                                   frame_obs, frame_match):

@@ -324,3 +324,57 @@ def test_budgeted_projection_search(matcher, oracle, seed, stereo, th):
         assert nm == nm_ref
         for x, y in zip(got, ref):
             assert np.array_equal(x, y)
+
+
+# ---- ORBmatcher::SearchByBoW (src/ORBmatcher.cc:270-404, :635-768) ----
+@pytest.mark.parametrize("seed", [61, 62, 63])
+def test_bow_search(matcher, oracle, seed):
+    """Both forms on frames of 2000 keypoints over 100 vocabulary nodes (what levelsup = 4 of a 10^6-word vocabulary
+    gives a Frame, src/Frame.cc ComputeBoW): every (keypoint, keypoint) pair of a shared node gets its distance on the
+    device; matches and nmatches equal the oracle's with and without the rotation check."""
+    from orb_slam_amd import ORBmatcher
+    from test_oracle_search import _bow_case
+    rng = np.random.default_rng(seed)
+    k1, d1, h1, fv1, k2, d2, h2, fv2 = _bow_case(rng, 2000, 2100, 100)
+    for ratio, ori in ((0.7, True), (0.75, False), (0.9, True)):
+        m = ORBmatcher(matcher._ex, nnratio=ratio, checkOri=ori)
+        nm_g, m_g = m.SearchByBoW(k1, d1, h1, fv1, k2, d2, fv2)
+        nm_o, m_o = oracle.search_by_bow_frame(k1, d1, h1, fv1, k2, d2, fv2, ratio, ori)
+        assert nm_g == nm_o and nm_g > 300 and np.array_equal(m_g, m_o)
+        nm_g, m_g = m.SearchByBoW_KeyFrames(k1, d1, h1, fv1, k2, d2, h2, fv2)
+        nm_o, m_o = oracle.search_by_bow_keyframes(k1, d1, h1, fv1, k2, d2, h2, fv2, ratio, ori)
+        assert nm_g == nm_o and nm_g > 250 and np.array_equal(m_g, m_o)
+    # nothing in common, nothing at all
+    m = ORBmatcher(matcher._ex, nnratio=0.7)
+    shifted = {k + 100000: v for k, v in fv2.items()}
+    assert m.SearchByBoW(k1, d1, h1, fv1, k2, d2, shifted)[0] == 0
+    assert m.SearchByBoW(k1, d1, h1, {}, k2, d2, fv2)[0] == 0
+    assert m.SearchByBoW(k1, d1, np.zeros(len(k1), np.uint8), fv1, k2, d2, fv2)[0] == 0
+    nm, mm = m.SearchByBoW(k1[:0], d1[:0], h1[:0], {}, k2, d2, fv2)
+    assert nm == 0 and (mm == -1).all()
+
+
+def test_bow_search_on_the_euroc_pair(oracle, euroc_left, euroc_right):
+    """Tracking::TrackReferenceKeyFrame (src/Tracking.cc, ORBmatcher matcher(0.7, true)): the left image as the
+    keyframe, the right one as the frame; nodes = a coarse hash of the descriptor standing in for the vocabulary
+    (equal on both sides for most true pairs)."""
+    from orb_slam_amd import ORBextractor, ORBmatcher
+    ex = ORBextractor(1000, 1.2, 8, 20, 7)
+    m = ORBmatcher(ex, nnratio=0.7, checkOri=True)
+    kl, dl = ex(euroc_left)
+    kr, dr = ex(euroc_right)
+
+    def nodes_of(d):
+        bits = np.unpackbits(d, axis=1)
+        return (bits[:, 0:64].sum(1) > 32).astype(np.int64) * 4 + (bits[:, 64:128].sum(1) > 32) * 2 + (bits[:, 128:192].sum(1) > 32)
+
+    def fv_of(d):
+        nd = nodes_of(d)
+        return {int(v): np.nonzero(nd == v)[0].tolist() for v in np.unique(nd)}
+
+    h = np.ones(len(kl), np.uint8)
+    h[::9] = 0
+    nm_g, m_g = m.SearchByBoW(kl, dl, h, fv_of(dl), kr, dr, fv_of(dr))
+    nm_o, m_o = oracle.search_by_bow_frame(kl, dl, h, fv_of(dl), kr, dr, fv_of(dr), 0.7, True)
+    assert nm_g == nm_o and nm_g > 100 and np.array_equal(m_g, m_o)
+    ex.close()

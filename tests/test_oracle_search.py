@@ -610,3 +610,121 @@ def test_budgeted_projection_search_at_its_two_deterministic_ends(oracle, seed, 
     assert (nm0, stop0) == (nm_py, extra["stopped_at"]) and 3 <= stop0 < M and nm0 <= 1
     for a, b in zip(zero, py):
         assert np.array_equal(a, b)
+
+
+# ---- ORBmatcher::SearchByBoW (src/ORBmatcher.cc:270-404 KeyFrame/Frame, :635-768 KeyFrame/KeyFrame) ----
+def _bow_case(rng, n1=600, n2=650, nodes=60, flip=0.03):
+    """two frames whose first min(n1, n2) keypoints correspond; a feature's vocabulary node is mostly the same on both
+    sides (as for a real vocabulary: similar descriptors fall into the same node), some land elsewhere"""
+    k1, d1, k2, d2 = _random_frames(rng, n1, n2, clusters=10)
+    n = min(n1, n2)
+    bits = np.unpackbits(d1[:n], axis=1)
+    d2[:n] = np.packbits(bits ^ (rng.random(bits.shape) < flip), axis=1)
+    k2["angle"][:n] = ((k1["angle"][:n] + rng.choice([0.0, 0.0, 0.0, 3.0, 100.0], n)) % 360).astype(np.float32)
+    node1 = rng.integers(0, nodes, n1) * 7 + 3
+    node2 = rng.integers(0, nodes, n2) * 7 + 3
+    same = rng.random(n) < 0.85
+    node2[:n][same] = node1[:n][same]
+    node2[node2 == 3] = 2                       # a node only side 2 has, below all of side 1's ...
+    node1[node1 == 10] = 11                     # ... and one only side 1 has: both lower_bound branches are taken
+    fv1 = {int(v): np.nonzero(node1 == v)[0][rng.permutation((node1 == v).sum())].tolist() for v in np.unique(node1)}
+    fv2 = {int(v): np.nonzero(node2 == v)[0][rng.permutation((node2 == v).sum())].tolist() for v in np.unique(node2)}
+    h1 = (rng.random(n1) < 0.8).astype(np.uint8)
+    h2 = (rng.random(n2) < 0.8).astype(np.uint8)
+    return k1, d1, h1, fv1, k2, d2, h2, fv2
+
+
+def _py_search_by_bow(k1, d1, h1, fv1, k2, d2, h2, fv2, ratio, ori, keyframes):
+    out = np.full(len(k1) if keyframes else len(k2), -1, np.int32)
+    taken = np.zeros(len(k2), bool)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    for node in sorted(set(fv1) & set(fv2)):
+        for i1 in fv1[node]:
+            if not h1[i1]:
+                continue
+            b1, b2, bi = 256, 256, -1
+            for i2 in fv2[node]:
+                if taken[i2] or (keyframes and not h2[i2]):
+                    continue
+                d = _ham(d1[i1], d2[i2])
+                if d < b1:
+                    b2, b1, bi = b1, d, i2
+                elif d < b2:
+                    b2 = d
+            if (b1 < 50 if keyframes else b1 <= 50) and np.float32(b1) < np.float32(ratio) * np.float32(b2):
+                taken[bi] = True
+                if keyframes:
+                    out[i1] = bi
+                else:
+                    out[bi] = i1
+                nm += 1
+                if ori:
+                    rot = np.float32(k1["angle"][i1]) - np.float32(k2["angle"][bi])
+                    if rot < 0:
+                        rot = np.float32(rot + np.float32(360))
+                    b = int(np.floor(float(np.float32(rot * np.float32(1.0 / 30))) + 0.5))
+                    hist[0 if b == 30 else b].append(i1 if keyframes else bi)
+    if ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: (-sizes[i], i))[:3]
+        keep = [order[0]] if sizes[order[0]] > 0 else []
+        for o_ in order[1:]:
+            if sizes[o_] > 0 and not (np.float32(sizes[o_]) < np.float32(0.1) * np.float32(sizes[order[0]])):
+                keep.append(o_)
+            else:
+                break
+        for b in range(30):
+            if b not in keep:
+                for j in hist[b]:
+                    out[j] = -1
+                    nm -= 1
+    return nm, out
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_bow_search_against_python_statement(oracle, seed):
+    rng = np.random.default_rng(400 + seed)
+    case = _bow_case(rng)
+    k1, d1, h1, fv1, k2, d2, h2, fv2 = case
+    for ratio, ori in ((0.7, True), (0.9, False)):
+        nm_o, m_o = oracle.search_by_bow_frame(k1, d1, h1, fv1, k2, d2, fv2, ratio, ori)
+        nm_p, m_p = _py_search_by_bow(*case, ratio, ori, False)
+        assert nm_o == nm_p and nm_o > 100 and np.array_equal(m_o, m_p)
+        nm_o, m_o = oracle.search_by_bow_keyframes(*case, ratio, ori)
+        nm_p, m_p = _py_search_by_bow(*case, ratio, ori, True)
+        assert nm_o == nm_p and nm_o > 80 and np.array_equal(m_o, m_p)
+
+
+def test_bow_search_rules(oracle):
+    k1 = _kps([(10, 10), (20, 20), (30, 30)], angle=[0.0, 0.0, 0.0])
+    k2 = _kps([(10, 10), (20, 20), (30, 30), (40, 40)], angle=[0.0, 0.0, 0.0, 0.0])
+    d1 = _desc_with_bits([0, 0, 0])
+    ones = np.ones(3, np.uint8)
+
+    def frame(bits2, fv1, fv2, h1=ones, ratio=0.7):
+        return oracle.search_by_bow_frame(k1, d1, h1, fv1, k2, _desc_with_bits(bits2), fv2, ratio, False)
+
+    def kfs(bits2, fv1, fv2, h2, ratio=0.7):
+        return oracle.search_by_bow_keyframes(k1, d1, ones, fv1, k2, _desc_with_bits(bits2), h2, fv2, ratio, False)
+
+    one_node = ({5: [0]}, {5: [0, 1]})
+    # best 20 against second 30: 20 < 0.7 * 30 accepts; against 28 it does not (20 >= 19.6)
+    assert frame([20, 30, 0, 0], *one_node)[1].tolist() == [0, -1, -1, -1]
+    assert frame([20, 28, 0, 0], *one_node)[0] == 0
+    # TH_LOW: 50 passes against a frame, not between keyframes (strictly below there)
+    assert frame([50, 200, 0, 0], *one_node)[0] == 1
+    assert kfs([50, 200, 0, 0], *one_node, np.ones(4, np.uint8))[0] == 0
+    assert kfs([49, 200, 0, 0], *one_node, np.ones(4, np.uint8))[1].tolist() == [0, -1, -1]
+    # features in different nodes never meet
+    assert frame([0, 200, 0, 0], {5: [0]}, {6: [0, 1]})[0] == 0
+    # a frame keypoint is taken once: the second keyframe keypoint of the node finds it gone and takes the next best
+    nm, m = frame([5, 40, 200, 200], {5: [0, 1]}, {5: [0, 1, 2]}, ratio=0.9)
+    assert nm == 2 and m.tolist() == [0, 1, -1, -1]
+    # a keyframe keypoint without a good map point does not search; a keypoint of the second keyframe without one is no candidate
+    assert frame([5, 200, 0, 0], *one_node, h1=np.array([0, 1, 1], np.uint8))[0] == 0
+    assert kfs([5, 30, 0, 0], *one_node, np.array([0, 1, 1, 1], np.uint8), ratio=0.9)[1].tolist() == [1, -1, -1]
+    # the node's stored order decides ties (strict <): the first of two equal candidates
+    assert frame([20, 20, 0, 0], {5: [0]}, {5: [1, 0]}, ratio=1.1)[1].tolist() == [-1, 0, -1, -1]
+    # empty feature vectors
+    assert frame([0, 0, 0, 0], {}, {5: [0]})[0] == 0 and frame([0, 0, 0, 0], {5: [0]}, {})[0] == 0

@@ -414,6 +414,19 @@ int orbx_search_by_projection_last(orbx_ctx *ctx, const orbx_keypoint *kps, cons
                                    const int32_t *lp_octave, const float *lp_angle, const uint32_t *lp_desc,
                                    const int32_t *lp_observations, int M, float th, float mbf, int forward, int backward,
                                    int check_orientation, int32_t *frame_obs, int32_t *frame_match, int *nmatches);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, th, ORBdist),
+ * src/ORBmatcher.cc:1595-1721 (Tracking::Relocalization), from the projected points on: per keypoint i of the keyframe
+ * kp_visible (its map point exists, is not bad, is not in sAlreadyFound, projects inside the image bounds and lies
+ * inside its scale-invariance distances, :1615-1644), kp_u / kp_v, kp_level = pMP->PredictScale(dist3D, &CurrentFrame),
+ * kp_angle = pKF->mvKeysUn[i].angle, kp_desc = pMP->GetDescriptor(), kp_observations = what frame_obs receives (>= 0).
+ * A keypoint of the current frame is out when it holds any map point (frame_obs[i2] >= 0, :1664-1665), levels
+ * [kp_level - 1, kp_level + 1], accepted with bestDist <= orb_dist (:1678); rotation check as in the call above. */
+int orbx_search_by_projection_keyframe(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, int N,
+                                       float min_x, float min_y, float inv_w, float inv_h,
+                                       const uint8_t *kp_visible, const float *kp_u, const float *kp_v,
+                                       const int32_t *kp_level, const float *kp_angle, const uint32_t *kp_desc,
+                                       const int32_t *kp_observations, int M, float th, int orb_dist,
+                                       int check_orientation, int32_t *frame_obs, int32_t *frame_match, int *nmatches);
 
 /* --- keypoint undistortion --------------------------------------------------- */
 /* Frame::UndistortKeyPoints / UndistortKeyPointsStereo, src/Frame.cc:745-852: the keypoint

@@ -2264,3 +2264,59 @@ int oo_search_by_bow_keyframes(const oo_keypoint *k1, const uint32_t *d1, const 
     free(vbMatched2); free(hist);
     return nmatches;
 }
+
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, KeyFrame *pKF, const set<MapPoint*> &sAlreadyFound, const float th,
+ * const int ORBdist), src/ORBmatcher.cc:1595-1721, from the point where a map point of the keyframe has passed the
+ * tests of :1615-1644 (kp_visible) and been projected (kp_u, kp_v) with its predicted level (kp_level).  frame_obs[i2]
+ * >= 0 stands for CurrentFrame.mvpMapPoints[i2] != NULL. */
+int oo_search_by_projection_keyframe(const oo_keypoint *kps, const uint32_t *desc, int N, const float *scale_factors,
+                                     float minX, float minY, float invW, float invH,
+                                     const uint8_t *kp_visible, const float *kp_u, const float *kp_v,
+                                     const int32_t *kp_level, const float *kp_angle, const uint32_t *kp_desc,
+                                     const int32_t *kp_observations, int M, float th, int ORBdist, int check_orientation,
+                                     int32_t *frame_obs, int32_t *frame_match)
+{
+    int nmatches = 0;
+    int *hist = (int *)calloc((size_t)OO_HISTO_LENGTH * (size_t)(N > 0 ? N : 1), sizeof(int));
+    int hn[OO_HISTO_LENGTH] = {0};
+    int32_t *list = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    for (int i = 0; i < M; i++) {
+        if (!kp_visible[i]) continue;                                      /* :1615-1644 */
+        const int nPredictedLevel = kp_level[i];
+        const float radius = th * scale_factors[nPredictedLevel];          /* :1649 */
+        const int32_t qmin = nPredictedLevel - 1, qmax = nPredictedLevel + 1;
+        int32_t off[2];
+        const int n = oo_features_in_area(kps, N, minX, minY, invW, invH, &kp_u[i], &kp_v[i], &radius, &qmin, &qmax, 1,
+                                          off, list, N);                   /* :1651 */
+        if (n == 0) continue;                                              /* :1653-1654 */
+        int bestDist = 256, bestIdx2 = -1;
+        for (int k = 0; k < n; k++) {                                      /* :1661-1676 */
+            const int i2 = list[k];
+            if (frame_obs[i2] >= 0) continue;                              /* :1664-1665 */
+            const int dist = oo_hamming(kp_desc + 8 * (size_t)i, desc + 8 * (size_t)i2);
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= ORBdist) {                                         /* :1678 */
+            frame_match[bestIdx2] = i;                                     /* :1680 */
+            frame_obs[bestIdx2] = kp_observations[i];
+            nmatches++;
+            if (check_orientation) {                                       /* :1683-1693 */
+                const int bin = rot_bin(kp_angle[i], kps[bestIdx2].angle);
+                hist[bin * N + hn[bin]++] = bestIdx2;
+            }
+        }
+    }
+    if (check_orientation) {                                               /* :1699-1718 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(hn, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int j = 0; j < hn[i]; j++) {
+                    frame_match[hist[i * N + j]] = -1;
+                    frame_obs[hist[i * N + j]] = -1;
+                    nmatches--;
+                }
+    }
+    free(hist); free(list);
+    return nmatches;
+}

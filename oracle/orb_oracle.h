@@ -303,6 +303,15 @@ int oo_search_by_bow_keyframes(const oo_keypoint *k1, const uint32_t *d1, const 
                                const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
                                float nnratio, int check_orientation, int32_t *matches12);
 
+/* ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1595-1721 (relocalisation),
+ * from the projected points on; frame_obs[i2] >= 0 = the keypoint holds a map point.  Returns nmatches. */
+int oo_search_by_projection_keyframe(const oo_keypoint *kps, const uint32_t *desc, int N, const float *scale_factors,
+                                     float minX, float minY, float invW, float invH,
+                                     const uint8_t *kp_visible, const float *kp_u, const float *kp_v,
+                                     const int32_t *kp_level, const float *kp_angle, const uint32_t *kp_desc,
+                                     const int32_t *kp_observations, int M, float th, int ORBdist, int check_orientation,
+                                     int32_t *frame_obs, int32_t *frame_match);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

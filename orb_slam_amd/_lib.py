@@ -77,6 +77,8 @@ SIGNATURES = {
     "orbx_search_by_bow_frame": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _i, _vp, _ip]),
     "orbx_search_by_bow_keyframes": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, _i,
                                           _vp, _ip]),
+    "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i,
+                                                _vp, _vp, _ip]),
     "orbx_search_by_projection_last": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                             _f, _f, _i, _i, _i, _vp, _vp, _ip]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,

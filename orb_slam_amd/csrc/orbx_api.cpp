@@ -2100,12 +2100,15 @@ int orbx_search_by_bow_keyframes(orbx_ctx* c, const orbx_keypoint* k1, const uin
                          nodes2, nnratio, check_orientation, true, matches12, nmatches);
 }
 
-int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+// The projection searches that keep only the best candidate: against the last frame (src/ORBmatcher.cc:1440-1593; a
+// keypoint is out when its map point has observations, the accepted distance is TH_HIGH) and against a keyframe in
+// relocalisation (:1595-1721; a keypoint is out when it holds any map point, the accepted distance is the caller's).
+static int projected_points_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
                                    float min_x, float min_y, float inv_w, float inv_h, const uint8_t* lp_visible,
                                    const float* lp_u, const float* lp_v, const float* lp_invzc, const int32_t* lp_octave,
                                    const float* lp_angle, const uint32_t* lp_desc, const int32_t* lp_observations, int M,
-                                   float th, float mbf, int forward, int backward, int check_orientation,
-                                   int32_t* frame_obs, int32_t* frame_match, int* nmatches)
+                                   float th, float mbf, int forward, int backward, int check_orientation, int max_dist,
+                                   bool any_point_blocks, int32_t* frame_obs, int32_t* frame_match, int* nmatches)
 {
     if (!c || !nmatches) return ORBX_ERR_INVALID;
     *nmatches = 0;
@@ -2114,7 +2117,7 @@ int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const 
     if (!kps || !desc || !lp_visible || !lp_u || !lp_v || !lp_octave || !lp_desc || !lp_observations || !frame_obs ||
         !frame_match || (u_right && !lp_invzc) || (check_orientation && !lp_angle))
         return fail(c, ORBX_ERR_INVALID, "null buffer");
-    constexpr int kThHigh = 100, kHisto = 30;          // TH_HIGH, HISTO_LENGTH (src/ORBmatcher.cc:38-39)
+    constexpr int kHisto = 30;                         // HISTO_LENGTH (src/ORBmatcher.cc:39)
     // the queries: the visible map points of the last frame, window th * mvScaleFactors[octave] (:1499), the level range
     // by the direction of motion (:1503-1508)
     std::vector<int32_t> qi;
@@ -2156,7 +2159,7 @@ int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const 
         int bestDist = 256, bestIdx2 = -1;
         for (int k = off[q]; k < off[q + 1]; k++) {
             const int i2 = idx[k];
-            if (frame_obs[i2] > 0) continue;                                  // :1521-1523
+            if (any_point_blocks ? frame_obs[i2] >= 0 : frame_obs[i2] > 0) continue;   // :1664-1665, :1521-1523
             if (u_right && u_right[i2] > 0) {                                 // :1525-1531
                 const float ur = lp_u[i] - mbf * lp_invzc[i];
                 const float er = fabsf(ur - u_right[i2]);
@@ -2165,7 +2168,7 @@ int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const 
             const int d = dist[k];
             if (d < bestDist) { bestDist = d; bestIdx2 = i2; }
         }
-        if (bestDist <= kThHigh) {                                            // :1544
+        if (bestDist <= max_dist) {                                           // :1544, :1678
             frame_match[bestIdx2] = i;
             frame_obs[bestIdx2] = lp_observations[i];
             nm++;
@@ -2194,6 +2197,30 @@ int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const 
     return ORBX_OK;
 }
 
+int orbx_search_by_projection_last(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N,
+                                   float min_x, float min_y, float inv_w, float inv_h, const uint8_t* lp_visible,
+                                   const float* lp_u, const float* lp_v, const float* lp_invzc, const int32_t* lp_octave,
+                                   const float* lp_angle, const uint32_t* lp_desc, const int32_t* lp_observations, int M,
+                                   float th, float mbf, int forward, int backward, int check_orientation,
+                                   int32_t* frame_obs, int32_t* frame_match, int* nmatches)
+{
+    return projected_points_search(c, kps, desc, u_right, N, min_x, min_y, inv_w, inv_h, lp_visible, lp_u, lp_v, lp_invzc,
+                                   lp_octave, lp_angle, lp_desc, lp_observations, M, th, mbf, forward, backward,
+                                   check_orientation, 100 /* TH_HIGH, src/ORBmatcher.cc:38 */, false, frame_obs, frame_match,
+                                   nmatches);
+}
+
+int orbx_search_by_projection_keyframe(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x,
+                                       float min_y, float inv_w, float inv_h, const uint8_t* kp_visible, const float* kp_u,
+                                       const float* kp_v, const int32_t* kp_level, const float* kp_angle,
+                                       const uint32_t* kp_desc, const int32_t* kp_observations, int M, float th, int orb_dist,
+                                       int check_orientation, int32_t* frame_obs, int32_t* frame_match, int* nmatches)
+{
+    if (c && (orb_dist < 0 || orb_dist > 256)) return fail(c, ORBX_ERR_INVALID, "orb_dist must be in [0, 256]");
+    return projected_points_search(c, kps, desc, nullptr, N, min_x, min_y, inv_w, inv_h, kp_visible, kp_u, kp_v, nullptr,
+                                   kp_level, kp_angle, kp_desc, kp_observations, M, th, 0.0f, 0, 0, check_orientation, orb_dist,
+                                   true, frame_obs, frame_match, nmatches);
+}
 
 // K, dist, R, P -> the model the kernel evaluates; RR = P(:, 0:3) * R as cv::undistortPoints forms it
 static int undistort_model(orbx_ctx* c, const double* K, const double* dist, int ndist, const double* R, const double* P,

@@ -356,6 +356,29 @@ class ORBmatcher:
             len(n2), self.mfNNratio, int(bool(self.mbCheckOrientation)), out.ctypes.data, C.byref(nm)))
         return nm.value, out
 
+    def SearchByProjectionKeyFrame(self, keys, desc, grid, kf, th, ORBdist, frame_obs, frame_match):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) (src/ORBmatcher.cc:1595-1721) from
+        the projected points on.  kf: dict of per-keypoint arrays of the keyframe (visible, u, v, level, angle,
+        descriptor, Observations); frame_obs (-1 = the keypoint holds no map point) / frame_match: int32 arrays over the
+        current keypoints, updated in place.  Returns nmatches."""
+        kps = np.ascontiguousarray(keys, KP_DTYPE)
+        d = _desc(desc)
+        for a in (frame_obs, frame_match):
+            if a.dtype != np.int32 or not a.flags.c_contiguous or len(a) < len(kps):
+                raise ValueError("frame arrays must be contiguous int32 arrays of N entries")
+        vis = np.ascontiguousarray(kf["visible"], np.uint8)
+        u, v, ang = (np.ascontiguousarray(kf[k], np.float32) for k in ("u", "v", "angle"))
+        lvl = np.ascontiguousarray(kf["level"], np.int32)
+        obs = np.ascontiguousarray(kf["Observations"], np.int32)
+        kd = _desc(kf["descriptor"])
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_projection_keyframe(
+            self._ctx, kps.ctypes.data, d.ctypes.data, len(kps), grid[0], grid[1], grid[2], grid[3], vis.ctypes.data,
+            u.ctypes.data, v.ctypes.data, lvl.ctypes.data, ang.ctypes.data, kd.ctypes.data, obs.ctypes.data, len(vis),
+            float(th), int(ORBdist), int(bool(self.mbCheckOrientation)), frame_obs.ctypes.data, frame_match.ctypes.data,
+            C.byref(nm)))
+        return nm.value
+
     def SearchByProjectionLast(self, keys, desc, mvuRight, grid, last, th, mbf, bForward, bBackward, frame_obs, frame_match):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) (src/ORBmatcher.cc:1440-1593)
         from :1496 on.  last: dict of per-keypoint arrays of the last frame (visible, u, v, invzc, octave, angle,

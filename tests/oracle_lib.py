@@ -122,6 +122,8 @@ class Oracle:
                                                _i32p, _i32p, _ci, _f, _ci, _i32p]
         lib.oo_search_by_bow_keyframes.argtypes = [C.c_void_p, _u32p, _u8p, _ci, _i32p, _i32p, _i32p, _ci, C.c_void_p, _u32p,
                                                    _u8p, _ci, _i32p, _i32p, _i32p, _ci, _f, _ci, _i32p]
+        lib.oo_search_by_projection_keyframe.argtypes = [C.c_void_p, _u32p, _ci, _f32p, _f, _f, _f, _f, _u8p, _f32p, _f32p, _i32p,
+                                                         _f32p, _u32p, _i32p, _ci, _f, _ci, _ci, _i32p, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -505,6 +507,23 @@ class Oracle:
                                                  _ptr(o2, _i32p), _ptr(i2, _i32p), c2, nnratio, int(check_ori),
                                                  _ptr(out, _i32p))
         return nm, out[:len(k1)]
+
+    def search_by_projection_keyframe(self, kps, desc, grid, kf, th, orb_dist, check_ori, frame_obs, frame_match):
+        """ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist) from the projected points on;
+        kf: dict of per-keypoint arrays of the keyframe (visible, u, v, level, angle, descriptor, Observations)"""
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        sf = self.tables()["scale"]
+        vis = np.ascontiguousarray(kf["visible"], np.uint8)
+        u, v, ang = (np.ascontiguousarray(kf[k], np.float32) for k in ("u", "v", "angle"))
+        lvl = np.ascontiguousarray(kf["level"], np.int32)
+        obs = np.ascontiguousarray(kf["Observations"], np.int32)
+        kd = np.ascontiguousarray(kf["descriptor"], np.uint8).reshape(-1, 32)
+        return self.lib.oo_search_by_projection_keyframe(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), len(kps), _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3],
+            _ptr(vis, _u8p), _ptr(u, _f32p), _ptr(v, _f32p), _ptr(lvl, _i32p), _ptr(ang, _f32p),
+            _ptr(kd.view(np.uint32), _u32p), _ptr(obs, _i32p), len(vis), th, int(orb_dist), int(check_ori),
+            _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p))
 
     def search_by_projection_last(self, kps, desc, u_right, grid, last, th, mbf, forward, backward, check_ori,
                                   frame_obs, frame_match):

@@ -378,3 +378,29 @@ def test_bow_search_on_the_euroc_pair(oracle, euroc_left, euroc_right):
     nm_o, m_o = oracle.search_by_bow_frame(kl, dl, h, fv_of(dl), kr, dr, fv_of(dr), 0.7, True)
     assert nm_g == nm_o and nm_g > 100 and np.array_equal(m_g, m_o)
     ex.close()
+
+
+# ---- ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1595-1721 ----
+@pytest.mark.parametrize("seed,th,orb_dist", [(71, 10.0, 100), (72, 3.0, 64), (73, 10.0, 30)])
+def test_relocalisation_projection_search(matcher, oracle, seed, th, orb_dist):
+    """Tracking::Relocalization (src/Tracking.cc: SearchByProjection(mCurrentFrame, vpCandidateKFs[i], sFound, 10, 100) and
+    (…, 3, 64)) on 3000-keypoint frames with 2500 projected keyframe points"""
+    from orb_slam_amd import ORBmatcher
+    from test_oracle_search import _keyframe_points
+    rng = np.random.default_rng(seed)
+    kps, desc, _, _ = _random_frames(rng, 3000, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    kf = _keyframe_points(rng, kps, desc, 2500)
+    obs0 = rng.choice([-1, -1, -1, 0, 2], len(kps)).astype(np.int32)
+    for ori in (True, False):
+        m = ORBmatcher(matcher._ex, nnratio=0.9, checkOri=ori)
+        g = (obs0.copy(), np.full(len(kps), -1, np.int32))
+        o = (obs0.copy(), np.full(len(kps), -1, np.int32))
+        nm_g = m.SearchByProjectionKeyFrame(kps, desc, GRID, kf, th, orb_dist, *g)
+        nm_o = oracle.search_by_projection_keyframe(kps, desc, GRID, kf, th, orb_dist, ori, *o)
+        assert nm_g == nm_o and nm_g > 100
+        assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+        assert (g[1][obs0 >= 0] == -1).all()                 # a keypoint that held a map point was never given another
+    hidden = dict(kf, visible=np.zeros(2500, np.uint8))
+    g = (obs0.copy(), np.full(len(kps), -1, np.int32))
+    assert ORBmatcher(matcher._ex).SearchByProjectionKeyFrame(kps, desc, GRID, hidden, th, orb_dist, *g) == 0

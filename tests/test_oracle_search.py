@@ -728,3 +728,43 @@ def test_bow_search_rules(oracle):
     assert frame([20, 20, 0, 0], {5: [0]}, {5: [1, 0]}, ratio=1.1)[1].tolist() == [-1, 0, -1, -1]
     # empty feature vectors
     assert frame([0, 0, 0, 0], {}, {5: [0]})[0] == 0 and frame([0, 0, 0, 0], {5: [0]}, {})[0] == 0
+
+
+# ---- ORBmatcher::SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1595-1721 ----
+def _keyframe_points(rng, kps, desc, M):
+    last = _last_frame_points(rng, kps, desc, M)
+    return {"visible": last["visible"], "u": last["u"], "v": last["v"], "level": last["octave"], "angle": last["angle"],
+            "descriptor": last["descriptor"], "Observations": rng.choice([0, 1, 4], M).astype(np.int32)}
+
+
+@pytest.mark.parametrize("seed,th,orb_dist", [(1, 10.0, 100), (2, 3.0, 64)])
+def test_relocalisation_projection_search(oracle, seed, th, orb_dist):
+    """Against the last-frame search, which differs in three places only (any held map point blocks a keypoint, no
+    right-image gate, the caller's distance bound): with keypoints that hold either nothing or a point with
+    observations, ORBdist = TH_HIGH and a monocular frame the two must agree; then the differences one by one."""
+    rng = np.random.default_rng(500 + seed)
+    kps, desc, _, _ = _random_frames(rng, 500, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    kf = _keyframe_points(rng, kps, desc, 350)
+    kf["Observations"][:] = 2
+    last = {"visible": kf["visible"], "u": kf["u"], "v": kf["v"], "invzc": np.ones(350, np.float32), "octave": kf["level"],
+            "angle": kf["angle"], "descriptor": kf["descriptor"], "Observations": kf["Observations"]}
+    obs0 = rng.choice([-1, -1, -1, 3], len(kps)).astype(np.int32)
+    for ori in (True, False):
+        a = (obs0.copy(), np.full(len(kps), -1, np.int32))
+        b = (obs0.copy(), np.full(len(kps), -1, np.int32))
+        nm_a = oracle.search_by_projection_keyframe(kps, desc, GRID, kf, th, 100, ori, *a)
+        nm_b = oracle.search_by_projection_last(kps, desc, None, GRID, last, th, 0.0, False, False, ori, *b)
+        assert nm_a == nm_b and nm_a > 30
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # a keypoint holding a map point without observations: free for the last-frame search, taken here
+    obs1 = np.where(obs0 == 3, 0, obs0).astype(np.int32)
+    a = (obs1.copy(), np.full(len(kps), -1, np.int32))
+    oracle.search_by_projection_keyframe(kps, desc, GRID, kf, th, 100, False, *a)
+    assert (a[1][obs1 == 0] == -1).all()
+    # the distance bound
+    fo, fm = np.full(len(kps), -1, np.int32), np.full(len(kps), -1, np.int32)
+    nm_small = oracle.search_by_projection_keyframe(kps, desc, GRID, kf, th, orb_dist // 4, False, fo, fm)
+    m = fm >= 0
+    d = np.unpackbits(desc[m] ^ kf["descriptor"][fm[m]], axis=1).sum(1)
+    assert nm_small == m.sum() and (d <= orb_dist // 4).all() and 0 < nm_small

@@ -428,6 +428,54 @@ int orbx_search_by_projection_keyframe(orbx_ctx *ctx, const orbx_keypoint *kps, 
                                        const int32_t *kp_observations, int M, float th, int orb_dist,
                                        int check_orientation, int32_t *frame_obs, int32_t *frame_match, int *nmatches);
 
+/* --- the searches of the mapping and loop-closing threads ---------------------------------------------------------------
+ * Each takes the map points from the place where the reference has projected them: visible[i] = every `continue` before
+ * the window search passed (bad / already found / behind the camera / outside the image / outside the scale-invariance
+ * distances / viewing angle), u / v = the projection, level = PredictScale(...).  A point looks at the keypoints of levels
+ * [level - 1, level] inside th * mvScaleFactors[level] (GetFeaturesInArea without levels + the loops' own level test). */
+/* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched,
+ * int th), src/ORBmatcher.cc:406-518 (LoopClosing::ComputeSim3).  kf_matched[idx] >= 0 = vpMatched[idx] != NULL, in/out
+ * (:491-492, :512: an accepted point stores 1); kf_match[idx] = the point of vpPoints this call put there (initialise to -1). */
+int orbx_search_by_projection_sim3(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, int N,
+                                   float min_x, float min_y, float inv_w, float inv_h,
+                                   const uint8_t *mp_visible, const float *mp_u, const float *mp_v, const int32_t *mp_level,
+                                   const uint32_t *mp_desc, int M, int th, int32_t *kf_matched, int32_t *kf_match, int *nmatches);
+/* The search of ORBmatcher::Fuse: gate != 0 the form of src/ORBmatcher.cc:937-1087 (LocalMapping::SearchInNeighbors; reprojection
+ * test :1026-1050 with u_right = pKF->mvuRight -- NULL for a monocular keyframe -- and mp_ur = u - bf * invz, the context's
+ * mvInvLevelSigma2), gate == 0 the Sim3 form of :1089-1212 (LoopClosing::SearchAndFuse).  best_idx[i] = bestIdx where bestDist <=
+ * TH_LOW (:1064, :1194), else -1; best_dist[i] = bestDist (256: nothing compared).  The search of a point does not depend on
+ * the other points; replacing or adding the observation (:1066-1081, :1196-1206) stays with the caller, in order. */
+int orbx_fuse_search(orbx_ctx *ctx, const orbx_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                     float min_x, float min_y, float inv_w, float inv_h,
+                     const uint8_t *mp_visible, const float *mp_u, const float *mp_v, const float *mp_ur,
+                     const int32_t *mp_level, const uint32_t *mp_desc, int M, float th, int gate,
+                     int32_t *best_idx, int32_t *best_dist, int *nfused);
+/* ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1214-1438: p1_* = the map points of pKF1 (per keypoint of pKF1) projected into pKF2
+ * with the Sim3 and searched among pKF2's keypoints (k2, d2), p2_* the other way round; both keyframes share the grid
+ * constants.  matches12[i1] = idx2 for the pairs that chose each other (:1419-1435), -1 elsewhere; *nfound = the return value. */
+int orbx_search_by_sim3(orbx_ctx *ctx, const orbx_keypoint *k1, const uint32_t *d1, int n1,
+                        const orbx_keypoint *k2, const uint32_t *d2, int n2,
+                        float min_x, float min_y, float inv_w, float inv_h,
+                        const uint8_t *p1_visible, const float *p1_u, const float *p1_v, const int32_t *p1_level,
+                        const uint32_t *p1_desc,
+                        const uint8_t *p2_visible, const float *p2_u, const float *p2_v, const int32_t *p2_level,
+                        const uint32_t *p2_desc, float th, int32_t *matches12, int *nfound);
+/* ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:770-935 (LocalMapping::CreateNewMapPoints).  has_point = the keypoint
+ * already holds a map point (:815, :838), stereo = mvuRight >= 0, feature vectors as in orbx_search_by_bow_frame, F12 = the
+ * fundamental matrix row-major as float, (ex, ey) = the epipole in the second image (:776-783); mvScaleFactors and
+ * mvLevelSigma2 are the context's.  The device computes the distance of every pair sharing a node; the host applies
+ * `dist > TH_LOW || dist > bestDist` (:851: the last of equal candidates wins), the epipole distance (:856-862),
+ * CheckDistEpipolarLine (:251-268) and the rotation histogram.  The reference never sets its vbMatched2, so a keypoint of the
+ * second keyframe can be matched to several of the first; so here.  matches12[n1] = vMatches12. */
+int orbx_search_for_triangulation(orbx_ctx *ctx, const orbx_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1,
+                                  const uint8_t *stereo1, int n1,
+                                  const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                  const orbx_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2,
+                                  const uint8_t *stereo2, int n2,
+                                  const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                  const float *F12, float ex, float ey, int only_stereo, int check_orientation,
+                                  int32_t *matches12, int *nmatches);
+
 /* --- keypoint undistortion --------------------------------------------------- */
 /* Frame::UndistortKeyPoints / UndistortKeyPointsStereo, src/Frame.cc:745-852: the keypoint
  * coordinates go through cv::undistortPoints(pts, K, dist, R, P) (fisheye = 0) or

@@ -348,6 +348,20 @@ struct FeatureVector {
     }
 };
 
+// Map points as the searches of the mapping and loop-closing threads see them once projected: visible = every test before
+// the window search passed, (u, v) = the projection, ur = u - bf / z (Fuse on a stereo keyframe only), level = PredictScale
+struct ProjectedPoints {
+    std::vector<uint8_t> visible;
+    std::vector<float> u, v, ur;
+    std::vector<int32_t> level;
+    std::vector<uint8_t> descriptors;     // 32 bytes per map point
+    bool consistent() const
+    {
+        const size_t M = visible.size();
+        return u.size() == M && v.size() == M && level.size() == M && descriptors.size() == 32 * M && (ur.empty() || ur.size() == M);
+    }
+};
+
 // What ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) reads of each map point of
 // the last frame after projecting it (src/ORBmatcher.cc:1478-1510): visible = non-null, not an outlier, invzc >= 0
 // and (u, v) inside the image bounds; octave / angle = LastFrame.mvKeys[i]; parallel arrays of one length
@@ -545,6 +559,87 @@ public:
                                              last.angle.data(), reinterpret_cast<const uint32_t*>(last.descriptors.data()),
                                              last.Observations.data(), (int)M, th, mbf, bForward ? 1 : 0, bBackward ? 1 : 0,
                                              mbCheckOrientation ? 1 : 0, frame_obs.data(), frame_match.data(), &nmatches));
+        return nmatches;
+    }
+
+    // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:406-518, from the projected points on.
+    // kfMatched[idx] >= 0 = vpMatched[idx] is set (in/out); kfMatch[idx] = the point of `pts` this call stored there.
+    int SearchByProjection(const std::vector<orbx_keypoint>& kfKeysUn, const uint8_t* kfDesc, const FrameGrid& grid,
+                           const ProjectedPoints& pts, int th, std::vector<int32_t>& kfMatched, std::vector<int32_t>& kfMatch)
+    {
+        if (!pts.consistent() || kfMatched.size() != kfKeysUn.size() || kfMatch.size() != kfKeysUn.size())
+            throw std::invalid_argument("array lengths do not agree");
+        int nmatches = 0;
+        check(orbx_search_by_projection_sim3(ex_.context(), kfKeysUn.data(), reinterpret_cast<const uint32_t*>(kfDesc),
+                                             (int)kfKeysUn.size(), grid.mnMinX, grid.mnMinY, grid.mfGridElementWidthInv,
+                                             grid.mfGridElementHeightInv, pts.visible.data(), pts.u.data(), pts.v.data(),
+                                             pts.level.data(), reinterpret_cast<const uint32_t*>(pts.descriptors.data()),
+                                             (int)pts.visible.size(), th, kfMatched.data(), kfMatch.data(), &nmatches));
+        return nmatches;
+    }
+
+    // The search of Fuse(pKF, vpMapPoints, th) (src/ORBmatcher.cc:937-1087, reprojectionGate = true; mvuRight = nullptr for a
+    // monocular keyframe) and of Fuse(pKF, Scw, vpPoints, th, vpReplacePoint) (:1089-1212, reprojectionGate = false):
+    // bestIdx[i] = the keypoint map point i fuses with (-1: none), bestDist[i] = its distance.  Returns nFused; the
+    // Replace / AddObservation step stays with the caller.
+    int Fuse(const std::vector<orbx_keypoint>& kfKeysUn, const uint8_t* kfDesc, const std::vector<float>* mvuRight,
+             const FrameGrid& grid, const ProjectedPoints& pts, float th, bool reprojectionGate, std::vector<int32_t>& bestIdx,
+             std::vector<int32_t>& bestDist)
+    {
+        if (!pts.consistent() || (mvuRight && (mvuRight->size() != kfKeysUn.size() || pts.ur.size() != pts.visible.size())))
+            throw std::invalid_argument("array lengths do not agree");
+        bestIdx.assign(pts.visible.size(), -1);
+        bestDist.assign(pts.visible.size(), 256);
+        int nFused = 0;
+        check(orbx_fuse_search(ex_.context(), kfKeysUn.data(), reinterpret_cast<const uint32_t*>(kfDesc),
+                               mvuRight ? mvuRight->data() : nullptr, (int)kfKeysUn.size(), grid.mnMinX, grid.mnMinY,
+                               grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, pts.visible.data(), pts.u.data(),
+                               pts.v.data(), mvuRight ? pts.ur.data() : nullptr, pts.level.data(),
+                               reinterpret_cast<const uint32_t*>(pts.descriptors.data()), (int)pts.visible.size(), th,
+                               reprojectionGate ? 1 : 0, bestIdx.data(), bestDist.data(), &nFused));
+        return nFused;
+    }
+
+    // SearchBySim3, src/ORBmatcher.cc:1214-1438: pts1 = pKF1's map points (one entry per keypoint of pKF1) projected into
+    // pKF2, pts2 the other way round.  vpMatches12[i1] = the keypoint of pKF2 chosen mutually, -1 elsewhere.
+    int SearchBySim3(const std::vector<orbx_keypoint>& keysUn1, const uint8_t* desc1, const std::vector<orbx_keypoint>& keysUn2,
+                     const uint8_t* desc2, const FrameGrid& grid, const ProjectedPoints& pts1, const ProjectedPoints& pts2,
+                     float th, std::vector<int32_t>& vpMatches12)
+    {
+        if (!pts1.consistent() || !pts2.consistent() || pts1.visible.size() != keysUn1.size() || pts2.visible.size() != keysUn2.size())
+            throw std::invalid_argument("array lengths do not agree");
+        vpMatches12.assign(keysUn1.size(), -1);
+        int nFound = 0;
+        check(orbx_search_by_sim3(ex_.context(), keysUn1.data(), reinterpret_cast<const uint32_t*>(desc1), (int)keysUn1.size(),
+                                  keysUn2.data(), reinterpret_cast<const uint32_t*>(desc2), (int)keysUn2.size(), grid.mnMinX,
+                                  grid.mnMinY, grid.mfGridElementWidthInv, grid.mfGridElementHeightInv, pts1.visible.data(),
+                                  pts1.u.data(), pts1.v.data(), pts1.level.data(),
+                                  reinterpret_cast<const uint32_t*>(pts1.descriptors.data()), pts2.visible.data(), pts2.u.data(),
+                                  pts2.v.data(), pts2.level.data(), reinterpret_cast<const uint32_t*>(pts2.descriptors.data()), th,
+                                  vpMatches12.data(), &nFound));
+        return nFound;
+    }
+
+    // SearchForTriangulation, src/ORBmatcher.cc:770-935.  hasPoint = the keypoint already holds a map point, stereo =
+    // mvuRight >= 0, F12 row-major, (ex, ey) = the epipole in the second image.  vMatches12[i1] = partner in pKF2 or -1.
+    int SearchForTriangulation(const std::vector<orbx_keypoint>& keysUn1, const uint8_t* desc1, const std::vector<uint8_t>& hasPoint1,
+                               const std::vector<uint8_t>& stereo1, const FeatureVector& featVec1,
+                               const std::vector<orbx_keypoint>& keysUn2, const uint8_t* desc2, const std::vector<uint8_t>& hasPoint2,
+                               const std::vector<uint8_t>& stereo2, const FeatureVector& featVec2, const float F12[9], float ex,
+                               float ey, bool bOnlyStereo, std::vector<int32_t>& vMatches12)
+    {
+        if (hasPoint1.size() != keysUn1.size() || stereo1.size() != keysUn1.size() || hasPoint2.size() != keysUn2.size() ||
+            stereo2.size() != keysUn2.size())
+            throw std::invalid_argument("array lengths do not agree");
+        vMatches12.assign(keysUn1.size(), -1);
+        int nmatches = 0;
+        check(orbx_search_for_triangulation(ex_.context(), keysUn1.data(), reinterpret_cast<const uint32_t*>(desc1), hasPoint1.data(),
+                                            stereo1.data(), (int)keysUn1.size(), featVec1.node.data(), featVec1.off.data(),
+                                            featVec1.idx.data(), (int)featVec1.node.size(), keysUn2.data(),
+                                            reinterpret_cast<const uint32_t*>(desc2), hasPoint2.data(), stereo2.data(),
+                                            (int)keysUn2.size(), featVec2.node.data(), featVec2.off.data(), featVec2.idx.data(),
+                                            (int)featVec2.node.size(), F12, ex, ey, bOnlyStereo ? 1 : 0, mbCheckOrientation ? 1 : 0,
+                                            vMatches12.data(), &nmatches));
         return nmatches;
     }
 

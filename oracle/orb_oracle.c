@@ -2320,3 +2320,209 @@ int oo_search_by_projection_keyframe(const oo_keypoint *kps, const uint32_t *des
     free(hist); free(list);
     return nmatches;
 }
+
+/* ------------------------------------------------------------------------- *
+ * The searches of the mapping and loop-closing threads, each from the point where the reference has projected
+ * its map points (visible[i] = every `continue` before the window search passed).
+ * ------------------------------------------------------------------------- */
+/* best keypoint of levels [level - 1, level] inside the window (the inner loops of :486-508, :1172-1191, :1311-1331):
+ * `gate` adds the reprojection test of Fuse, :1026-1050.  Returns bestIdx, *best = bestDist. */
+static int window_best(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N,
+                       const float *scale_factors, const float *inv_sigma2, float minX, float minY, float invW, float invH,
+                       float u, float v, float ur, int level, const uint32_t *mp_desc, float th, int gate,
+                       const int32_t *blocked, int32_t *list, int *best)
+{
+    const float radius = th * scale_factors[level];
+    const int32_t qmin = -1, qmax = -1;                                    /* GetFeaturesInArea(u, v, radius): every level */
+    int32_t off[2];
+    const int n = oo_features_in_area(kps, N, minX, minY, invW, invH, &u, &v, &radius, &qmin, &qmax, 1, off, list, N);
+    int bestDist = 256, bestIdx = -1;
+    for (int k = 0; k < n; k++) {
+        const int idx = list[k];
+        if (blocked && blocked[idx] >= 0) continue;                        /* :491-492 */
+        const int kpLevel = kps[idx].octave;
+        if (kpLevel < level - 1 || kpLevel > level) continue;              /* :496-497, :1023-1024, :1179, :1319 */
+        if (gate) {
+            if (u_right && u_right[idx] >= 0) {                            /* :1026-1039 */
+                const float ex = u - kps[idx].x, ey = v - kps[idx].y, er = ur - u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_sigma2[kpLevel] > 7.8) continue;
+            } else {                                                       /* :1040-1050 */
+                const float ex = u - kps[idx].x, ey = v - kps[idx].y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_sigma2[kpLevel] > 5.99) continue;
+            }
+        }
+        const int dist = oo_hamming(mp_desc, desc + 8 * (size_t)idx);
+        if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+    }
+    *best = bestDist;
+    return bestIdx;
+}
+
+/* ORBmatcher::SearchByProjection(KeyFrame *pKF, cv::Mat Scw, const vector<MapPoint*> &vpPoints, vector<MapPoint*> &vpMatched,
+ * int th), src/ORBmatcher.cc:406-518, from :473 on.  kf_matched[idx] >= 0 = vpMatched[idx] != NULL (in/out: an accepted
+ * point stores 1), kf_match[idx] = the point this call stored there.  Returns nmatches. */
+int oo_search_by_projection_sim3(const oo_keypoint *kps, const uint32_t *desc, int N, const float *scale_factors,
+                                 float minX, float minY, float invW, float invH, const uint8_t *mp_visible,
+                                 const float *mp_u, const float *mp_v, const int32_t *mp_level, const uint32_t *mp_desc,
+                                 int M, int th, int32_t *kf_matched, int32_t *kf_match)
+{
+    int nmatches = 0;
+    int32_t *list = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    for (int iMP = 0; iMP < M; iMP++) {
+        if (!mp_visible[iMP]) continue;
+        int bestDist;
+        const int bestIdx = window_best(kps, desc, NULL, N, scale_factors, NULL, minX, minY, invW, invH, mp_u[iMP], mp_v[iMP],
+                                        0.0f, mp_level[iMP], mp_desc + 8 * (size_t)iMP, (float)th, 0, kf_matched, list, &bestDist);
+        if (bestDist <= OO_TH_LOW) {                                       /* :510-514 */
+            kf_matched[bestIdx] = 1;
+            kf_match[bestIdx] = iMP;
+            nmatches++;
+        }
+    }
+    free(list);
+    return nmatches;
+}
+
+/* The search of ORBmatcher::Fuse: gate != 0 the form of :937-1087 (reprojection test; u_right = pKF->mvuRight or NULL for a
+ * monocular keyframe, mp_ur = u - bf * invz), gate == 0 the Sim3 form of :1089-1212.  best_idx[i] = bestIdx if bestDist <=
+ * TH_LOW (:1064, :1194) else -1, best_dist[i] = bestDist (256 when nothing was compared).  What happens to a fused point
+ * (Replace / AddObservation, :1066-1081) is the caller's map bookkeeping.  Returns nFused. */
+int oo_fuse_search(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N, const float *scale_factors,
+                   const float *inv_sigma2, float minX, float minY, float invW, float invH, const uint8_t *mp_visible,
+                   const float *mp_u, const float *mp_v, const float *mp_ur, const int32_t *mp_level,
+                   const uint32_t *mp_desc, int M, float th, int gate, int32_t *best_idx, int32_t *best_dist)
+{
+    int nFused = 0;
+    int32_t *list = (int32_t *)calloc((size_t)(N > 0 ? N : 1), sizeof(int32_t));
+    for (int i = 0; i < M; i++) {
+        best_idx[i] = -1;
+        best_dist[i] = 256;
+        if (!mp_visible[i]) continue;
+        int bestDist;
+        const int bestIdx = window_best(kps, desc, u_right, N, scale_factors, inv_sigma2, minX, minY, invW, invH, mp_u[i], mp_v[i],
+                                        mp_ur ? mp_ur[i] : 0.0f, mp_level[i], mp_desc + 8 * (size_t)i, th, gate, NULL, list,
+                                        &bestDist);
+        best_dist[i] = bestDist;
+        if (bestDist <= OO_TH_LOW) { best_idx[i] = bestIdx; nFused++; }
+    }
+    free(list);
+    return nFused;
+}
+
+/* ORBmatcher::SearchBySim3, src/ORBmatcher.cc:1214-1438, from the projected points on: p1_* = the map points of pKF1 seen
+ * from pKF2 (visible = exists, not matched yet, not bad, :1264-1295 passed), searched among pKF2's keypoints (k2, d2), and
+ * the other way round.  matches12[i1] = idx2 for the pairs that chose each other (:1419-1435), -1 elsewhere. */
+int oo_search_by_sim3(const oo_keypoint *k1, const uint32_t *d1, int n1, const oo_keypoint *k2, const uint32_t *d2, int n2,
+                      const float *scale_factors, float minX, float minY, float invW, float invH,
+                      const uint8_t *p1_visible, const float *p1_u, const float *p1_v, const int32_t *p1_level,
+                      const uint32_t *p1_desc, const uint8_t *p2_visible, const float *p2_u, const float *p2_v,
+                      const int32_t *p2_level, const uint32_t *p2_desc, float th, int32_t *matches12)
+{
+    int32_t *vnMatch1 = (int32_t *)calloc((size_t)(n1 > 0 ? n1 : 1), sizeof(int32_t));
+    int32_t *vnMatch2 = (int32_t *)calloc((size_t)(n2 > 0 ? n2 : 1), sizeof(int32_t));
+    int32_t *list = (int32_t *)calloc((size_t)((n1 > n2 ? n1 : n2) + 1), sizeof(int32_t));
+    for (int i1 = 0; i1 < n1; i1++) {
+        vnMatch1[i1] = -1;
+        if (!p1_visible[i1]) continue;
+        int bestDist;
+        const int bestIdx = window_best(k2, d2, NULL, n2, scale_factors, NULL, minX, minY, invW, invH, p1_u[i1], p1_v[i1], 0.0f,
+                                        p1_level[i1], p1_desc + 8 * (size_t)i1, th, 0, NULL, list, &bestDist);
+        if (bestDist <= OO_TH_HIGH) vnMatch1[i1] = bestIdx;                /* :1333-1336 */
+    }
+    for (int i2 = 0; i2 < n2; i2++) {
+        vnMatch2[i2] = -1;
+        if (!p2_visible[i2]) continue;
+        int bestDist;
+        const int bestIdx = window_best(k1, d1, NULL, n1, scale_factors, NULL, minX, minY, invW, invH, p2_u[i2], p2_v[i2], 0.0f,
+                                        p2_level[i2], p2_desc + 8 * (size_t)i2, th, 0, NULL, list, &bestDist);
+        if (bestDist <= OO_TH_HIGH) vnMatch2[i2] = bestIdx;                /* :1413-1416 */
+    }
+    int nFound = 0;
+    for (int i1 = 0; i1 < n1; i1++) {                                      /* :1419-1435 */
+        matches12[i1] = -1;
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nFound++; }
+    }
+    free(vnMatch1); free(vnMatch2); free(list);
+    return nFound;
+}
+
+/* ORBmatcher::CheckDistEpipolarLine, src/ORBmatcher.cc:251-268 (F12 row-major, float) */
+static int check_dist_epipolar_line(const oo_keypoint *kp1, const oo_keypoint *kp2, const float *F12, const float *sigma2)
+{
+    const float a = kp1->x * F12[0] + kp1->y * F12[3] + F12[6];
+    const float b = kp1->x * F12[1] + kp1->y * F12[4] + F12[7];
+    const float c = kp1->x * F12[2] + kp1->y * F12[5] + F12[8];
+    const float num = a * kp2->x + b * kp2->y + c;
+    const float den = a * a + b * b;
+    if (den == 0) return 0;
+    const float dsqr = num * num / den;
+    return dsqr < 3.84 * sigma2[kp2->octave];
+}
+
+/* ORBmatcher::SearchForTriangulation, src/ORBmatcher.cc:770-935.  has_point = the keypoint already holds a map point
+ * (:815, :838), stereo = mvuRight >= 0 (:818, :841), (ex, ey) = the epipole in the second image (:776-783), feature vectors
+ * as in oo_search_by_bow_frame.  The reference declares vbMatched2 and never sets it: a keypoint of the second keyframe can
+ * be the partner of several of the first.  matches12[n1] = vMatches12.  Returns nmatches. */
+int oo_search_for_triangulation(const oo_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1, const uint8_t *stereo1,
+                                int n1, const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                const oo_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2, const uint8_t *stereo2,
+                                const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                const float *scale_factors, const float *sigma2, const float *F12, float ex, float ey,
+                                int bOnlyStereo, int check_orientation, int32_t *matches12)
+{
+    int nmatches = 0;
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                        /* :791 */
+    int *hist = (int *)calloc((size_t)OO_HISTO_LENGTH * (size_t)(n1 > 0 ? n1 : 1), sizeof(int));
+    int hn[OO_HISTO_LENGTH] = {0};
+    int f1it = 0, f2it = 0;
+    while (f1it != nodes1 && f2it != nodes2) {
+        if (node1[f1it] == node2[f2it]) {
+            for (int i1 = off1[f1it]; i1 < off1[f1it + 1]; i1++) {
+                const int i1x = idx1[i1];
+                if (has_point1[i1x]) continue;                             /* :812-816 */
+                const int bStereo1 = stereo1[i1x];
+                if (bOnlyStereo && !bStereo1) continue;                    /* :820-822 */
+                int bestDist = OO_TH_LOW, bestIdx2 = -1;                   /* :828-829 */
+                for (int i2 = off2[f2it]; i2 < off2[f2it + 1]; i2++) {
+                    const int i2x = idx2[i2];
+                    if (has_point2[i2x]) continue;                         /* :838 (vbMatched2 is never set) */
+                    const int bStereo2 = stereo2[i2x];
+                    if (bOnlyStereo && !bStereo2) continue;                /* :843-845 */
+                    const int dist = oo_hamming(d1 + 8 * (size_t)i1x, d2 + 8 * (size_t)i2x);
+                    if (dist > OO_TH_LOW || dist > bestDist) continue;     /* :851-852 */
+                    if (!bStereo1 && !bStereo2) {                          /* :856-862 */
+                        const float distex = ex - k2[i2x].x, distey = ey - k2[i2x].y;
+                        if (distex * distex + distey * distey < 100 * scale_factors[k2[i2x].octave]) continue;
+                    }
+                    if (check_dist_epipolar_line(&k1[i1x], &k2[i2x], F12, sigma2)) { bestIdx2 = i2x; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {                                       /* :871-888 */
+                    matches12[i1x] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        const int bin = rot_bin(k1[i1x].angle, k2[bestIdx2].angle);
+                        hist[bin * n1 + hn[bin]++] = i1x;
+                    }
+                }
+            }
+            f1it++; f2it++;
+        } else if (node1[f1it] < node2[f2it]) {
+            f1it = fv_lower_bound(node1, nodes1, f1it, node2[f2it]);
+        } else {
+            f2it = fv_lower_bound(node2, nodes2, f2it, node1[f1it]);
+        }
+    }
+    if (check_orientation) {                                               /* :904-922 */
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        oo_three_maxima(hn, OO_HISTO_LENGTH, &ind1, &ind2, &ind3);
+        for (int i = 0; i < OO_HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j = 0; j < hn[i]; j++) { matches12[hist[i * n1 + j]] = -1; nmatches--; }
+        }
+    }
+    free(hist);
+    return nmatches;
+}

@@ -312,6 +312,29 @@ int oo_search_by_projection_keyframe(const oo_keypoint *kps, const uint32_t *des
                                      const int32_t *kp_observations, int M, float th, int ORBdist, int check_orientation,
                                      int32_t *frame_obs, int32_t *frame_match);
 
+/* The searches of the mapping and loop-closing threads, from the projected points on (visible = every test before the window
+ * search passed): SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) src/ORBmatcher.cc:406-518; the search of Fuse (:937-1087
+ * with gate != 0, :1089-1212 with gate == 0); SearchBySim3 :1214-1438; SearchForTriangulation :770-935. */
+int oo_search_by_projection_sim3(const oo_keypoint *kps, const uint32_t *desc, int N, const float *scale_factors,
+                                 float minX, float minY, float invW, float invH, const uint8_t *mp_visible,
+                                 const float *mp_u, const float *mp_v, const int32_t *mp_level, const uint32_t *mp_desc,
+                                 int M, int th, int32_t *kf_matched, int32_t *kf_match);
+int oo_fuse_search(const oo_keypoint *kps, const uint32_t *desc, const float *u_right, int N, const float *scale_factors,
+                   const float *inv_sigma2, float minX, float minY, float invW, float invH, const uint8_t *mp_visible,
+                   const float *mp_u, const float *mp_v, const float *mp_ur, const int32_t *mp_level,
+                   const uint32_t *mp_desc, int M, float th, int gate, int32_t *best_idx, int32_t *best_dist);
+int oo_search_by_sim3(const oo_keypoint *k1, const uint32_t *d1, int n1, const oo_keypoint *k2, const uint32_t *d2, int n2,
+                      const float *scale_factors, float minX, float minY, float invW, float invH,
+                      const uint8_t *p1_visible, const float *p1_u, const float *p1_v, const int32_t *p1_level,
+                      const uint32_t *p1_desc, const uint8_t *p2_visible, const float *p2_u, const float *p2_v,
+                      const int32_t *p2_level, const uint32_t *p2_desc, float th, int32_t *matches12);
+int oo_search_for_triangulation(const oo_keypoint *k1, const uint32_t *d1, const uint8_t *has_point1, const uint8_t *stereo1,
+                                int n1, const int32_t *node1, const int32_t *off1, const int32_t *idx1, int nodes1,
+                                const oo_keypoint *k2, const uint32_t *d2, const uint8_t *has_point2, const uint8_t *stereo2,
+                                const int32_t *node2, const int32_t *off2, const int32_t *idx2, int nodes2,
+                                const float *scale_factors, const float *sigma2, const float *F12, float ex, float ey,
+                                int bOnlyStereo, int check_orientation, int32_t *matches12);
+
 /* Frame::UndistortKeyPoints[Stereo], src/Frame.cc:745-852: cv::undistortPoints (fisheye = 0)
  * or cv::fisheye::undistortPoints (fisheye != 0) on n points (x, y interleaved).
  * K: 3x3 row-major camera matrix; dist: ndist (0, 4, 5, 8 or 12; fisheye: 4) coefficients;

@@ -79,6 +79,12 @@ SIGNATURES = {
                                           _vp, _ip]),
     "orbx_search_by_projection_keyframe": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _i,
                                                 _vp, _vp, _ip]),
+    "orbx_search_by_projection_sim3": (_i, [_vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _ip]),
+    "orbx_fuse_search": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i, _f, _i, _vp, _vp, _ip]),
+    "orbx_search_by_sim3": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _f, _vp, _ip]),
+    "orbx_search_for_triangulation": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                           _i, _vp, _f, _f, _i, _i, _vp, _ip]),
     "orbx_search_by_projection_last": (_i, [_vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i,
                                             _f, _f, _i, _i, _i, _vp, _vp, _ip]),
     "orbx_stereo_match_device": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f,

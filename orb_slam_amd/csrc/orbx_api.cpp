@@ -2222,6 +2222,268 @@ int orbx_search_by_projection_keyframe(orbx_ctx* c, const orbx_keypoint* kps, co
                                    true, frame_obs, frame_match, nmatches);
 }
 
+// ---------------------------------------------------------------------------
+// The searches of the mapping and loop-closing threads.  Each map point looks for the most similar keypoint of levels
+// [level - 1, level] inside its window; the device forms the lists (GetFeaturesInArea order) with every distance, the
+// host applies what differs between the routines.
+// ---------------------------------------------------------------------------
+struct WindowLists {
+    std::vector<int32_t> qi, off, idx;
+    std::vector<uint16_t> dist;
+};
+static int window_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y, float inv_w,
+                        float inv_h, const uint8_t* visible, const float* u, const float* v, const int32_t* level,
+                        const uint32_t* mp_desc, int M, float th, WindowLists& wl)
+{
+    wl.qi.clear();
+    for (int i = 0; i < M; i++) {
+        if (!visible[i]) continue;
+        if (level[i] < 0 || level[i] >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "predicted level out of range");
+        wl.qi.push_back(i);
+    }
+    const int Q = (int)wl.qi.size();
+    wl.off.assign(1, 0);
+    wl.idx.clear();
+    wl.dist.clear();
+    if (Q == 0 || N == 0) { wl.off.assign((size_t)Q + 1, 0); return ORBX_OK; }
+    std::vector<float> qx(Q), qy(Q), qr(Q);
+    std::vector<int32_t> qmin(Q), qmax(Q);
+    std::vector<uint32_t> qd((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) {
+        const int i = wl.qi[q];
+        qx[q] = u[i];
+        qy[q] = v[i];
+        qr[q] = th * c->p.scale[level[i]];
+        qmin[q] = level[i] - 1;     // GetFeaturesInArea without levels + the loops' own level test = this level range
+        qmax[q] = level[i];
+        std::memcpy(&qd[(size_t)q * 8], mp_desc + (size_t)i * 8, 32);
+    }
+    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
+    if (rc != ORBX_OK) return rc;
+    return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, wl.off, wl.idx, wl.dist);
+}
+
+int orbx_search_by_projection_sim3(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y,
+                                   float inv_w, float inv_h, const uint8_t* mp_visible, const float* mp_u, const float* mp_v,
+                                   const int32_t* mp_level, const uint32_t* mp_desc, int M, int th, int32_t* kf_matched,
+                                   int32_t* kf_match, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (N == 0 || M == 0) return ORBX_OK;
+    if (!kps || !desc || !mp_visible || !mp_u || !mp_v || !mp_level || !mp_desc || !kf_matched || !kf_match)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    WindowLists wl;
+    int rc = window_lists(c, kps, desc, N, min_x, min_y, inv_w, inv_h, mp_visible, mp_u, mp_v, mp_level, mp_desc, M, (float)th, wl);
+    if (rc != ORBX_OK) return rc;
+    int nm = 0;
+    for (size_t q = 0; q < wl.qi.size(); q++) {
+        int bestDist = 256, bestIdx = -1;
+        for (int k = wl.off[q]; k < wl.off[q + 1]; k++) {
+            const int idx = wl.idx[k];
+            if (kf_matched[idx] >= 0) continue;                               // src/ORBmatcher.cc:491-492
+            if ((int)wl.dist[k] < bestDist) { bestDist = wl.dist[k]; bestIdx = idx; }
+        }
+        if (bestDist <= 50) {                                                 // TH_LOW, :510-514
+            kf_matched[bestIdx] = 1;
+            kf_match[bestIdx] = wl.qi[q];
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
+int orbx_fuse_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, const float* u_right, int N, float min_x,
+                     float min_y, float inv_w, float inv_h, const uint8_t* mp_visible, const float* mp_u, const float* mp_v,
+                     const float* mp_ur, const int32_t* mp_level, const uint32_t* mp_desc, int M, float th, int gate,
+                     int32_t* best_idx, int32_t* best_dist, int* nfused)
+{
+    if (!c || !nfused) return ORBX_ERR_INVALID;
+    *nfused = 0;
+    if (N < 0 || M < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (M == 0) return ORBX_OK;
+    if (!best_idx || !best_dist) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < M; i++) { best_idx[i] = -1; best_dist[i] = 256; }
+    if (N == 0) return ORBX_OK;
+    if (!kps || !desc || !mp_visible || !mp_u || !mp_v || !mp_level || !mp_desc || (gate && u_right && !mp_ur))
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    WindowLists wl;
+    int rc = window_lists(c, kps, desc, N, min_x, min_y, inv_w, inv_h, mp_visible, mp_u, mp_v, mp_level, mp_desc, M, th, wl);
+    if (rc != ORBX_OK) return rc;
+    int nf = 0;
+    for (size_t q = 0; q < wl.qi.size(); q++) {
+        const int i = wl.qi[q];
+        const float u = mp_u[i], v = mp_v[i];
+        int bestDist = 256, bestIdx = -1;
+        for (int k = wl.off[q]; k < wl.off[q + 1]; k++) {
+            const int idx = wl.idx[k];
+            if (gate) {                                                       // src/ORBmatcher.cc:1026-1050
+                const int kpLevel = kps[idx].octave;
+                if (kpLevel < 0 || kpLevel >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "keypoint octave out of range");
+                if (u_right && u_right[idx] >= 0) {
+                    const float ex = u - kps[idx].x, ey = v - kps[idx].y, er = mp_ur[i] - u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * c->p.inv_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kps[idx].x, ey = v - kps[idx].y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * c->p.inv_sigma2[kpLevel] > 5.99) continue;
+                }
+            }
+            if ((int)wl.dist[k] < bestDist) { bestDist = wl.dist[k]; bestIdx = idx; }
+        }
+        best_dist[i] = bestDist;
+        if (bestDist <= 50) { best_idx[i] = bestIdx; nf++; }                 // TH_LOW, :1064, :1194
+    }
+    *nfused = nf;
+    return ORBX_OK;
+}
+
+int orbx_search_by_sim3(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d1, int n1, const orbx_keypoint* k2,
+                        const uint32_t* d2, int n2, float min_x, float min_y, float inv_w, float inv_h,
+                        const uint8_t* p1_visible, const float* p1_u, const float* p1_v, const int32_t* p1_level,
+                        const uint32_t* p1_desc, const uint8_t* p2_visible, const float* p2_u, const float* p2_v,
+                        const int32_t* p2_level, const uint32_t* p2_desc, float th, int32_t* matches12, int* nfound)
+{
+    if (!c || !nfound) return ORBX_ERR_INVALID;
+    *nfound = 0;
+    if (n1 < 0 || n2 < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (n1 > 0 && !matches12) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < n1; i++) matches12[i] = -1;
+    if (n1 == 0 || n2 == 0) return ORBX_OK;
+    if (!k1 || !d1 || !k2 || !d2 || !p1_visible || !p1_u || !p1_v || !p1_level || !p1_desc || !p2_visible || !p2_u || !p2_v ||
+        !p2_level || !p2_desc)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    std::vector<int32_t> vnMatch1(n1, -1), vnMatch2(n2, -1);
+    auto half = [&](const orbx_keypoint* kps, const uint32_t* desc, int N, const uint8_t* vis, const float* u, const float* v,
+                    const int32_t* lvl, const uint32_t* pd, int M, std::vector<int32_t>& out) -> int {
+        WindowLists wl;
+        int rc = window_lists(c, kps, desc, N, min_x, min_y, inv_w, inv_h, vis, u, v, lvl, pd, M, th, wl);
+        if (rc != ORBX_OK) return rc;
+        for (size_t q = 0; q < wl.qi.size(); q++) {
+            int bestDist = 0x7fffffff, bestIdx = -1;
+            for (int k = wl.off[q]; k < wl.off[q + 1]; k++)
+                if ((int)wl.dist[k] < bestDist) { bestDist = wl.dist[k]; bestIdx = wl.idx[k]; }
+            if (bestDist <= 100) out[wl.qi[q]] = bestIdx;                     // TH_HIGH, src/ORBmatcher.cc:1333, :1413
+        }
+        return ORBX_OK;
+    };
+    int rc = half(k2, d2, n2, p1_visible, p1_u, p1_v, p1_level, p1_desc, n1, vnMatch1);
+    if (rc != ORBX_OK) return rc;
+    rc = half(k1, d1, n1, p2_visible, p2_u, p2_v, p2_level, p2_desc, n2, vnMatch2);
+    if (rc != ORBX_OK) return rc;
+    int nf = 0;
+    for (int i1 = 0; i1 < n1; i1++) {                                         // :1419-1435
+        const int idx2 = vnMatch1[i1];
+        if (idx2 >= 0 && vnMatch2[idx2] == i1) { matches12[i1] = idx2; nf++; }
+    }
+    *nfound = nf;
+    return ORBX_OK;
+}
+
+int orbx_search_for_triangulation(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d1, const uint8_t* has_point1,
+                                  const uint8_t* stereo1, int n1, const int32_t* node1, const int32_t* off1, const int32_t* idx1,
+                                  int nodes1, const orbx_keypoint* k2, const uint32_t* d2, const uint8_t* has_point2,
+                                  const uint8_t* stereo2, int n2, const int32_t* node2, const int32_t* off2, const int32_t* idx2,
+                                  int nodes2, const float* F12, float ex, float ey, int only_stereo, int check_orientation,
+                                  int32_t* matches12, int* nmatches)
+{
+    if (!c || !nmatches) return ORBX_ERR_INVALID;
+    *nmatches = 0;
+    if (n1 < 0 || n2 < 0 || nodes1 < 0 || nodes2 < 0) return fail(c, ORBX_ERR_INVALID, "negative size");
+    if (n1 > 0 && !matches12) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 0; i < n1; i++) matches12[i] = -1;                           // src/ORBmatcher.cc:791
+    if (n1 == 0 || n2 == 0 || nodes1 == 0 || nodes2 == 0) return ORBX_OK;
+    if (!k1 || !d1 || !has_point1 || !stereo1 || !node1 || !off1 || !idx1 || !k2 || !d2 || !has_point2 || !stereo2 || !node2 ||
+        !off2 || !idx2 || !F12)
+        return fail(c, ORBX_ERR_INVALID, "null buffer");
+    for (int i = 1; i < nodes1; i++) if (node1[i] <= node1[i - 1]) return fail(c, ORBX_ERR_INVALID, "node ids must ascend");
+    for (int i = 1; i < nodes2; i++) if (node2[i] <= node2[i - 1]) return fail(c, ORBX_ERR_INVALID, "node ids must ascend");
+    for (int i = 0; i < off1[nodes1]; i++) if (idx1[i] < 0 || idx1[i] >= n1) return fail(c, ORBX_ERR_INVALID, "feature index outside side 1");
+    for (int i = 0; i < off2[nodes2]; i++) if (idx2[i] < 0 || idx2[i] >= n2) return fail(c, ORBX_ERR_INVALID, "feature index outside side 2");
+    for (int i = 0; i < n2; i++)
+        if (k2[i].octave < 0 || k2[i].octave >= c->p.nlevels) return fail(c, ORBX_ERR_INVALID, "keypoint octave out of range");
+    constexpr int kHisto = 30, kThLow = 50;
+    // queries: the keypoints of the first keyframe without a map point (stereo ones only, if asked) in a node both have
+    std::vector<int32_t> qi, coff(1, 0), cidx;
+    for (int a = 0, b = 0; a < nodes1 && b < nodes2;) {
+        if (node1[a] < node2[b]) { a++; continue; }
+        if (node1[a] > node2[b]) { b++; continue; }
+        for (int i = off1[a]; i < off1[a + 1]; i++) {
+            const int i1 = idx1[i];
+            if (has_point1[i1] || (only_stereo && !stereo1[i1])) continue;    // :812-822
+            qi.push_back(i1);
+            cidx.insert(cidx.end(), idx2 + off2[b], idx2 + off2[b + 1]);
+            if (cidx.size() > 0x7fffffffu) return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates");
+            coff.push_back((int32_t)cidx.size());
+        }
+        a++;
+        b++;
+    }
+    const int Q = (int)qi.size();
+    if (Q == 0 || cidx.empty()) return ORBX_OK;
+    std::vector<uint32_t> qd((size_t)Q * 8);
+    for (int q = 0; q < Q; q++) std::memcpy(&qd[(size_t)q * 8], d1 + (size_t)qi[q] * 8, 32);
+    std::vector<uint16_t> dist(cidx.size());
+    int rc = orbx_hamming_csr(c, qd.data(), Q, d2, n2, coff.data(), cidx.data(), dist.data());
+    if (rc != ORBX_OK) return rc;
+    // ORBmatcher::CheckDistEpipolarLine, :251-268
+    auto epipolar_ok = [&](const orbx_keypoint& kp1, const orbx_keypoint& kp2) -> bool {
+        const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+        const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+        const float cc = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+        const float num = a * kp2.x + b * kp2.y + cc;
+        const float den = a * a + b * b;
+        if (den == 0) return false;
+        const float dsqr = num * num / den;
+        return dsqr < 3.84 * c->p.sigma2[kp2.octave];
+    };
+    int nm = 0;
+    std::vector<int32_t> rotHist[kHisto];
+    for (int q = 0; q < Q; q++) {
+        const int i1 = qi[q];
+        const bool bStereo1 = stereo1[i1] != 0;
+        int bestDist = kThLow, bestIdx2 = -1;                                 // :828-829
+        for (int k = coff[q]; k < coff[q + 1]; k++) {
+            const int i2 = cidx[k];
+            if (has_point2[i2]) continue;                                     // :838 (vbMatched2 is never set in the reference)
+            const bool bStereo2 = stereo2[i2] != 0;
+            if (only_stereo && !bStereo2) continue;                           // :843-845
+            const int d = dist[k];
+            if (d > kThLow || d > bestDist) continue;                         // :851-852
+            if (!bStereo1 && !bStereo2) {                                     // :856-862
+                const float distex = ex - k2[i2].x, distey = ey - k2[i2].y;
+                if (distex * distex + distey * distey < 100 * c->p.scale[k2[i2].octave]) continue;
+            }
+            if (epipolar_ok(k1[i1], k2[i2])) { bestIdx2 = i2; bestDist = d; }
+        }
+        if (bestIdx2 >= 0) {                                                  // :871-888
+            matches12[i1] = bestIdx2;
+            nm++;
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * (1.0f / kHisto));
+                if (bin == kHisto) bin = 0;
+                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
+                rotHist[bin].push_back(i1);
+            }
+        }
+    }
+    if (check_orientation) {                                                  // :904-922
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, kHisto, ind1, ind2, ind3);
+        for (int i = 0; i < kHisto; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return ORBX_OK;
+}
+
 // K, dist, R, P -> the model the kernel evaluates; RR = P(:, 0:3) * R as cv::undistortPoints forms it
 static int undistort_model(orbx_ctx* c, const double* K, const double* dist, int ndist, const double* R, const double* P,
                            int p_cols, int fisheye, UndistortModel& m)

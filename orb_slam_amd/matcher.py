@@ -379,6 +379,72 @@ class ORBmatcher:
             C.byref(nm)))
         return nm.value
 
+    @staticmethod
+    def _points(pts):
+        """dict of per-point arrays (visible, u, v, level, descriptor) -> contiguous arrays"""
+        return (np.ascontiguousarray(pts["visible"], np.uint8), np.ascontiguousarray(pts["u"], np.float32),
+                np.ascontiguousarray(pts["v"], np.float32), np.ascontiguousarray(pts["level"], np.int32), _desc(pts["descriptor"]))
+
+    def SearchByProjectionSim3(self, keys, desc, grid, pts, th, kf_matched, kf_match):
+        """ORBmatcher::SearchByProjection(pKF, Scw, vpPoints, vpMatched, th) (src/ORBmatcher.cc:406-518) from the projected
+        points on; kf_matched (>= 0: vpMatched[idx] is set) and kf_match (index into pts) are updated in place."""
+        kps, d = np.ascontiguousarray(keys, KP_DTYPE), _desc(desc)
+        vis, u, v, lvl, pd = self._points(pts)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_projection_sim3(
+            self._ctx, kps.ctypes.data, d.ctypes.data, len(kps), grid[0], grid[1], grid[2], grid[3], vis.ctypes.data,
+            u.ctypes.data, v.ctypes.data, lvl.ctypes.data, pd.ctypes.data, len(vis), int(th), kf_matched.ctypes.data,
+            kf_match.ctypes.data, C.byref(nm)))
+        return nm.value
+
+    def FuseSearch(self, keys, desc, mvuRight, grid, pts, th, gate=True):
+        """The search of ORBmatcher::Fuse (src/ORBmatcher.cc:937-1087 with gate, :1089-1212 without): returns (nFused,
+        best_idx, best_dist) per map point; pts carries "ur" (u - bf * invz) when mvuRight is given."""
+        kps, d = np.ascontiguousarray(keys, KP_DTYPE), _desc(desc)
+        ur = None if mvuRight is None else np.ascontiguousarray(mvuRight, np.float32)
+        vis, u, v, lvl, pd = self._points(pts)
+        pur = None if ur is None else np.ascontiguousarray(pts["ur"], np.float32)
+        bi, bd = np.zeros(len(vis), np.int32), np.zeros(len(vis), np.int32)
+        nf = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_fuse_search(
+            self._ctx, kps.ctypes.data, d.ctypes.data, ptr(ur), len(kps), grid[0], grid[1], grid[2], grid[3], vis.ctypes.data,
+            u.ctypes.data, v.ctypes.data, ptr(pur), lvl.ctypes.data, pd.ctypes.data, len(vis), float(th), int(bool(gate)),
+            bi.ctypes.data, bd.ctypes.data, C.byref(nf)))
+        return nf.value, bi, bd
+
+    def SearchBySim3(self, keys1, desc1, keys2, desc2, grid, pts1, pts2, th):
+        """ORBmatcher::SearchBySim3 (src/ORBmatcher.cc:1214-1438) from the projected points on: pts1 = pKF1's map points
+        projected into pKF2, pts2 the other way.  Returns (nFound, matches12)."""
+        k1, k2 = np.ascontiguousarray(keys1, KP_DTYPE), np.ascontiguousarray(keys2, KP_DTYPE)
+        d1, d2 = _desc(desc1), _desc(desc2)
+        a, b = self._points(pts1), self._points(pts2)
+        out = np.full(len(k1), -1, np.int32)
+        nf = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_by_sim3(
+            self._ctx, k1.ctypes.data, d1.ctypes.data, len(k1), k2.ctypes.data, d2.ctypes.data, len(k2), grid[0], grid[1],
+            grid[2], grid[3], *(x.ctypes.data for x in a), *(x.ctypes.data for x in b), float(th), out.ctypes.data,
+            C.byref(nf)))
+        return nf.value, out
+
+    def SearchForTriangulation(self, keys1, desc1, has_point1, stereo1, featvec1, keys2, desc2, has_point2, stereo2, featvec2,
+                               F12, epipole, bOnlyStereo=False):
+        """ORBmatcher::SearchForTriangulation (src/ORBmatcher.cc:770-935).  Returns (nmatches, vMatches12)."""
+        k1, k2 = np.ascontiguousarray(keys1, KP_DTYPE), np.ascontiguousarray(keys2, KP_DTYPE)
+        d1, d2 = _desc(desc1), _desc(desc2)
+        h1, h2 = np.ascontiguousarray(has_point1, np.uint8), np.ascontiguousarray(has_point2, np.uint8)
+        s1, s2 = np.ascontiguousarray(stereo1, np.uint8), np.ascontiguousarray(stereo2, np.uint8)
+        n1, o1, i1 = self.feature_vector(featvec1)
+        n2, o2, i2 = self.feature_vector(featvec2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        out = np.full(len(k1), -1, np.int32)
+        nm = C.c_int32()
+        check(self._lib, self._ctx, self._lib.orbx_search_for_triangulation(
+            self._ctx, k1.ctypes.data, d1.ctypes.data, h1.ctypes.data, s1.ctypes.data, len(k1), n1.ctypes.data, o1.ctypes.data,
+            i1.ctypes.data, len(n1), k2.ctypes.data, d2.ctypes.data, h2.ctypes.data, s2.ctypes.data, len(k2), n2.ctypes.data,
+            o2.ctypes.data, i2.ctypes.data, len(n2), F.ctypes.data, float(epipole[0]), float(epipole[1]), int(bool(bOnlyStereo)),
+            int(bool(self.mbCheckOrientation)), out.ctypes.data, C.byref(nm)))
+        return nm.value, out
+
     def SearchByProjectionLast(self, keys, desc, mvuRight, grid, last, th, mbf, bForward, bBackward, frame_obs, frame_match):
         """ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono, numVisibleMpt) (src/ORBmatcher.cc:1440-1593)
         from :1496 on.  last: dict of per-keypoint arrays of the last frame (visible, u, v, invzc, octave, angle,

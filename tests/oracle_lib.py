@@ -124,6 +124,15 @@ class Oracle:
                                                    _u8p, _ci, _i32p, _i32p, _i32p, _ci, _f, _ci, _i32p]
         lib.oo_search_by_projection_keyframe.argtypes = [C.c_void_p, _u32p, _ci, _f32p, _f, _f, _f, _f, _u8p, _f32p, _f32p, _i32p,
                                                          _f32p, _u32p, _i32p, _ci, _f, _ci, _ci, _i32p, _i32p]
+        lib.oo_search_by_projection_sim3.argtypes = [C.c_void_p, _u32p, _ci, _f32p, _f, _f, _f, _f, _u8p, _f32p, _f32p, _i32p, _u32p,
+                                                     _ci, _ci, _i32p, _i32p]
+        lib.oo_fuse_search.argtypes = [C.c_void_p, _u32p, _f32p, _ci, _f32p, _f32p, _f, _f, _f, _f, _u8p, _f32p, _f32p, _f32p,
+                                       _i32p, _u32p, _ci, _f, _ci, _i32p, _i32p]
+        lib.oo_search_by_sim3.argtypes = [C.c_void_p, _u32p, _ci, C.c_void_p, _u32p, _ci, _f32p, _f, _f, _f, _f, _u8p, _f32p, _f32p,
+                                          _i32p, _u32p, _u8p, _f32p, _f32p, _i32p, _u32p, _f, _i32p]
+        lib.oo_search_for_triangulation.argtypes = [C.c_void_p, _u32p, _u8p, _u8p, _ci, _i32p, _i32p, _i32p, _ci, C.c_void_p,
+                                                    _u32p, _u8p, _u8p, _i32p, _i32p, _i32p, _ci, _f32p, _f32p, _f32p, _f, _f,
+                                                    _ci, _ci, _i32p]
         self.nlevels = nlevels
         self.h = lib.oo_create(nfeatures, scale, nlevels, ini_th, min_th)
         if not self.h:
@@ -524,6 +533,71 @@ class Oracle:
             _ptr(vis, _u8p), _ptr(u, _f32p), _ptr(v, _f32p), _ptr(lvl, _i32p), _ptr(ang, _f32p),
             _ptr(kd.view(np.uint32), _u32p), _ptr(obs, _i32p), len(vis), th, int(orb_dist), int(check_ori),
             _ptr(frame_obs, _i32p), _ptr(frame_match, _i32p))
+
+    @staticmethod
+    def _pts(pts):
+        d = np.ascontiguousarray(pts["descriptor"], np.uint8).reshape(-1, 32)
+        return (np.ascontiguousarray(pts["visible"], np.uint8), np.ascontiguousarray(pts["u"], np.float32),
+                np.ascontiguousarray(pts["v"], np.float32), np.ascontiguousarray(pts["level"], np.int32), d)
+
+    def search_by_projection_sim3(self, kps, desc, grid, pts, th, kf_matched, kf_match):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        sf = self.tables()["scale"]
+        vis, u, v, lvl, pd = self._pts(pts)
+        return self.lib.oo_search_by_projection_sim3(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), len(kps), _ptr(sf, _f32p), grid[0], grid[1], grid[2], grid[3],
+            _ptr(vis, _u8p), _ptr(u, _f32p), _ptr(v, _f32p), _ptr(lvl, _i32p), _ptr(pd.view(np.uint32), _u32p), len(vis),
+            int(th), _ptr(kf_matched, _i32p), _ptr(kf_match, _i32p))
+
+    def fuse_search(self, kps, desc, u_right, grid, pts, th, gate):
+        kps = np.ascontiguousarray(kps, KP_DTYPE)
+        desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        t = self.tables()
+        ur = None if u_right is None else np.ascontiguousarray(u_right, np.float32)
+        vis, u, v, lvl, pd = self._pts(pts)
+        pur = None if ur is None else np.ascontiguousarray(pts["ur"], np.float32)
+        bi, bd = np.zeros(max(len(vis), 1), np.int32), np.zeros(max(len(vis), 1), np.int32)
+        nf = self.lib.oo_fuse_search(
+            kps.ctypes.data, _ptr(desc.view(np.uint32), _u32p), None if ur is None else _ptr(ur, _f32p), len(kps),
+            _ptr(t["scale"], _f32p), _ptr(t["inv_sigma2"], _f32p), grid[0], grid[1], grid[2], grid[3], _ptr(vis, _u8p),
+            _ptr(u, _f32p), _ptr(v, _f32p), None if pur is None else _ptr(pur, _f32p), _ptr(lvl, _i32p),
+            _ptr(pd.view(np.uint32), _u32p), len(vis), th, int(gate), _ptr(bi, _i32p), _ptr(bd, _i32p))
+        return nf, bi[:len(vis)], bd[:len(vis)]
+
+    def search_by_sim3(self, k1, d1, k2, d2, grid, pts1, pts2, th):
+        k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        sf = self.tables()["scale"]
+        a, b = self._pts(pts1), self._pts(pts2)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+
+        def args(p):
+            return (_ptr(p[0], _u8p), _ptr(p[1], _f32p), _ptr(p[2], _f32p), _ptr(p[3], _i32p), _ptr(p[4].view(np.uint32), _u32p))
+        nf = self.lib.oo_search_by_sim3(k1.ctypes.data, _ptr(d1.view(np.uint32), _u32p), len(k1), k2.ctypes.data,
+                                        _ptr(d2.view(np.uint32), _u32p), len(k2), _ptr(sf, _f32p), grid[0], grid[1], grid[2],
+                                        grid[3], *args(a), *args(b), th, _ptr(out, _i32p))
+        return nf, out[:len(k1)]
+
+    def search_for_triangulation(self, k1, d1, h1, s1, fv1, k2, d2, h2, s2, fv2, F12, epipole, only_stereo, check_ori):
+        k1, k2 = np.ascontiguousarray(k1, KP_DTYPE), np.ascontiguousarray(k2, KP_DTYPE)
+        d1 = np.ascontiguousarray(d1, np.uint8).reshape(-1, 32)
+        d2 = np.ascontiguousarray(d2, np.uint8).reshape(-1, 32)
+        h1, h2 = np.ascontiguousarray(h1, np.uint8), np.ascontiguousarray(h2, np.uint8)
+        s1, s2 = np.ascontiguousarray(s1, np.uint8), np.ascontiguousarray(s2, np.uint8)
+        t = self.tables()
+        n1, o1, i1, c1 = self._fv(fv1)
+        n2, o2, i2, c2 = self._fv(fv2)
+        F = np.ascontiguousarray(F12, np.float32).reshape(9)
+        out = np.full(max(len(k1), 1), -1, np.int32)
+        nm = self.lib.oo_search_for_triangulation(
+            k1.ctypes.data, _ptr(d1.view(np.uint32), _u32p), _ptr(h1, _u8p), _ptr(s1, _u8p), len(k1), _ptr(n1, _i32p),
+            _ptr(o1, _i32p), _ptr(i1, _i32p), c1, k2.ctypes.data, _ptr(d2.view(np.uint32), _u32p), _ptr(h2, _u8p),
+            _ptr(s2, _u8p), _ptr(n2, _i32p), _ptr(o2, _i32p), _ptr(i2, _i32p), c2, _ptr(t["scale"], _f32p),
+            _ptr(t["sigma2"], _f32p), _ptr(F, _f32p), float(epipole[0]), float(epipole[1]), int(only_stereo), int(check_ori),
+            _ptr(out, _i32p))
+        return nm, out[:len(k1)]
 
     def search_by_projection_last(self, kps, desc, u_right, grid, last, th, mbf, forward, backward, check_ori,
                                   frame_obs, frame_match):

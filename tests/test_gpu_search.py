@@ -404,3 +404,75 @@ def test_relocalisation_projection_search(matcher, oracle, seed, th, orb_dist):
     hidden = dict(kf, visible=np.zeros(2500, np.uint8))
     g = (obs0.copy(), np.full(len(kps), -1, np.int32))
     assert ORBmatcher(matcher._ex).SearchByProjectionKeyFrame(kps, desc, GRID, hidden, th, orb_dist, *g) == 0
+
+
+# ---- the searches of the mapping and loop-closing threads (src/ORBmatcher.cc:406-518, :937-1212, :1214-1438, :770-935) ----
+def _big_window_case(oracle, seed, n=3000, m=2500):
+    from test_oracle_search import _projected_points
+    rng = np.random.default_rng(seed)
+    kps, desc, _, _ = _random_frames(rng, n, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    return rng, kps, desc, _projected_points(rng, kps, desc, m)
+
+
+@pytest.mark.parametrize("seed,th", [(81, 10), (82, 4)])
+def test_sim3_projection_search(matcher, oracle, seed, th):
+    rng, kps, desc, pts = _big_window_case(oracle, seed)
+    matched0 = rng.choice([-1, -1, -1, 1], len(kps)).astype(np.int32)
+    g = (matched0.copy(), np.full(len(kps), -1, np.int32))
+    o = (matched0.copy(), np.full(len(kps), -1, np.int32))
+    nm_g = matcher.SearchByProjectionSim3(kps, desc, GRID, pts, th, *g)
+    nm_o = oracle.search_by_projection_sim3(kps, desc, GRID, pts, th, *o)
+    assert nm_g == nm_o and nm_g > 300
+    assert np.array_equal(g[0], o[0]) and np.array_equal(g[1], o[1])
+    hidden = dict(pts, visible=np.zeros(len(pts["u"]), np.uint8))
+    assert matcher.SearchByProjectionSim3(kps, desc, GRID, hidden, th, *g) == 0
+
+
+@pytest.mark.parametrize("seed,stereo,gate,th", [(83, True, True, 3.0), (84, False, True, 3.0), (85, False, False, 4.0),
+                                                 (86, True, True, 10.0)])
+def test_fuse_search(matcher, oracle, seed, stereo, gate, th):
+    rng, kps, desc, pts = _big_window_case(oracle, seed)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.uniform(2, 40, len(kps)).astype(np.float32), -1).astype(np.float32)
+    nf_g, bi_g, bd_g = matcher.FuseSearch(kps, desc, u_right, GRID, pts, th, gate)
+    nf_o, bi_o, bd_o = oracle.fuse_search(kps, desc, u_right, GRID, pts, th, gate)
+    assert nf_g == nf_o and nf_g > 300
+    assert np.array_equal(bi_g, bi_o) and np.array_equal(bd_g, bd_o)
+    nf, bi, bd = matcher.FuseSearch(kps[:0], desc[:0], None, GRID, pts, th, gate)
+    assert nf == 0 and (bi == -1).all() and (bd == 256).all()
+
+
+@pytest.mark.parametrize("seed", [87, 88])
+def test_sim3_search(matcher, oracle, seed):
+    rng = np.random.default_rng(seed)
+    k1, d1, k2, d2 = _random_frames(rng, 2500, 2600, clusters=10)
+    k1["octave"] = rng.integers(0, 8, len(k1))
+    k2["octave"] = rng.integers(0, 8, len(k2))
+    n = len(k1)
+    k2["x"][:n], k2["y"][:n], k2["octave"][:n] = k1["x"] + 1, k1["y"] - 1, k1["octave"]
+    bits = np.unpackbits(d1, axis=1)
+    d2[:n] = np.packbits(bits ^ (rng.random(bits.shape) < 0.03), axis=1)
+    pts1 = {"visible": (rng.random(len(k1)) < 0.85).astype(np.uint8), "u": k2["x"][:n].copy(), "v": k2["y"][:n].copy(),
+            "level": k1["octave"].astype(np.int32), "descriptor": d1}
+    pts2 = {"visible": (rng.random(len(k2)) < 0.85).astype(np.uint8),
+            "u": np.concatenate([k1["x"], k2["x"][n:]]).astype(np.float32),
+            "v": np.concatenate([k1["y"], k2["y"][n:]]).astype(np.float32),
+            "level": k2["octave"].astype(np.int32), "descriptor": d2}
+    nf_g, m_g = matcher.SearchBySim3(k1, d1, k2, d2, GRID, pts1, pts2, 7.5)
+    nf_o, m_o = oracle.search_by_sim3(k1, d1, k2, d2, GRID, pts1, pts2, 7.5)
+    assert nf_g == nf_o and nf_g > 800 and np.array_equal(m_g, m_o)
+
+
+@pytest.mark.parametrize("seed", [89, 90, 91])
+def test_triangulation_search(matcher, oracle, seed):
+    from orb_slam_amd import ORBmatcher
+    from test_oracle_search import _triangulation_case
+    rng = np.random.default_rng(seed)
+    case = _triangulation_case(rng, 2000, 2100, 100)
+    for only_stereo, ori in ((False, True), (True, False), (False, False)):
+        m = ORBmatcher(matcher._ex, nnratio=0.6, checkOri=ori)     # LocalMapping::CreateNewMapPoints: ORBmatcher matcher(0.6, false)
+        nm_g, m_g = m.SearchForTriangulation(*case, only_stereo)
+        nm_o, m_o = oracle.search_for_triangulation(*case, only_stereo, ori)
+        assert nm_g == nm_o and np.array_equal(m_g, m_o) and nm_g > (60 if only_stereo else 200)

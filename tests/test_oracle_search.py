@@ -768,3 +768,216 @@ def test_relocalisation_projection_search(oracle, seed, th, orb_dist):
     m = fm >= 0
     d = np.unpackbits(desc[m] ^ kf["descriptor"][fm[m]], axis=1).sum(1)
     assert nm_small == m.sum() and (d <= orb_dist // 4).all() and 0 < nm_small
+
+
+# ---- the searches of the mapping and loop-closing threads (src/ORBmatcher.cc:406-518, :937-1212, :1214-1438, :770-935) ----
+def _projected_points(rng, kps, desc, M, flip=0.05):
+    pick = rng.integers(0, len(kps), M)
+    bits = np.unpackbits(desc[pick], axis=1)
+    u = (kps["x"][pick] + rng.normal(0, 1.5, M)).astype(np.float32)
+    return {"visible": (rng.random(M) < 0.9).astype(np.uint8), "u": u,
+            "v": (kps["y"][pick] + rng.normal(0, 1.5, M)).astype(np.float32),
+            "ur": (u - rng.uniform(2, 40, M)).astype(np.float32),
+            "level": np.clip(kps["octave"][pick] + rng.integers(0, 2, M), 0, 7).astype(np.int32),
+            "descriptor": np.packbits(bits ^ (rng.random(bits.shape) < flip), axis=1)}
+
+
+def _py_window_best(kps, desc, u_right, grid, pts, i, th, sf, inv_s2, gate, blocked):
+    lvl = int(pts["level"][i])
+    radius = np.float32(np.float32(th) * sf[lvl])
+    best, bi = 256, -1
+    for idx in _py_features_in_area(kps, grid, pts["u"][i], pts["v"][i], radius, -1, -1):
+        if blocked is not None and blocked[idx] >= 0:
+            continue
+        kl = int(kps["octave"][idx])
+        if kl < lvl - 1 or kl > lvl:
+            continue
+        if gate:
+            ex = np.float32(pts["u"][i] - kps["x"][idx])
+            ey = np.float32(pts["v"][i] - kps["y"][idx])
+            if u_right is not None and u_right[idx] >= 0:
+                er = np.float32(pts["ur"][i] - u_right[idx])
+                e2 = np.float32(np.float32(np.float32(ex * ex) + np.float32(ey * ey)) + np.float32(er * er))
+                if float(np.float32(e2 * inv_s2[kl])) > 7.8:
+                    continue
+            else:
+                e2 = np.float32(np.float32(ex * ex) + np.float32(ey * ey))
+                if float(np.float32(e2 * inv_s2[kl])) > 5.99:
+                    continue
+        d = _ham(pts["descriptor"][i], desc[idx])
+        if d < best:
+            best, bi = d, idx
+    return bi, best
+
+
+def _window_case(oracle, seed, n=450, m=380):
+    rng = np.random.default_rng(600 + seed)
+    kps, desc, _, _ = _random_frames(rng, n, 1, clusters=10)
+    kps["octave"] = rng.integers(0, 8, len(kps))
+    t = oracle.tables()
+    return rng, kps, desc, t["scale"], t["inv_sigma2"], _projected_points(rng, kps, desc, m)
+
+
+@pytest.mark.parametrize("seed,th", [(1, 10), (2, 4)])
+def test_sim3_projection_search_against_python_statement(oracle, seed, th):
+    rng, kps, desc, sf, is2, pts = _window_case(oracle, seed)
+    matched0 = rng.choice([-1, -1, -1, 1], len(kps)).astype(np.int32)
+    a = (matched0.copy(), np.full(len(kps), -1, np.int32))
+    nm = oracle.search_by_projection_sim3(kps, desc, GRID, pts, th, *a)
+    b = (matched0.copy(), np.full(len(kps), -1, np.int32))
+    nm_py = 0
+    for i in range(len(pts["u"])):
+        if not pts["visible"][i]:
+            continue
+        bi, best = _py_window_best(kps, desc, None, GRID, pts, i, th, sf, is2, False, b[0])
+        if best <= 50:
+            b[0][bi], b[1][bi] = 1, i
+            nm_py += 1
+    assert nm == nm_py and nm > 30
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert (a[1][matched0 >= 0] == -1).all()
+
+
+@pytest.mark.parametrize("seed,stereo,gate,th", [(1, True, True, 3.0), (2, False, True, 3.0), (3, False, False, 4.0)])
+def test_fuse_search_against_python_statement(oracle, seed, stereo, gate, th):
+    rng, kps, desc, sf, is2, pts = _window_case(oracle, seed)
+    u_right = None
+    if stereo:
+        u_right = np.where(rng.random(len(kps)) < 0.6, kps["x"] - rng.uniform(2, 40, len(kps)).astype(np.float32), -1).astype(np.float32)
+    nf, bi, bd = oracle.fuse_search(kps, desc, u_right, GRID, pts, th, gate)
+    nf_py = 0
+    for i in range(len(pts["u"])):
+        want = (-1, 256)
+        if pts["visible"][i]:
+            want = _py_window_best(kps, desc, u_right, GRID, pts, i, th, sf, is2, gate, None)
+        assert bd[i] == want[1] and bi[i] == (want[0] if want[1] <= 50 else -1), i
+        nf_py += want[1] <= 50
+    assert nf == nf_py and nf > 30
+    if gate:          # the gate did reject candidates somewhere: without it more points fuse or some find a closer keypoint
+        nf2, bi2, bd2 = oracle.fuse_search(kps, desc, u_right, GRID, pts, th, False)
+        assert (bd2 < bd).any()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_sim3_search_against_python_statement(oracle, seed):
+    rng = np.random.default_rng(700 + seed)
+    k1, d1, k2, d2 = _random_frames(rng, 400, 420, clusters=8)
+    k1["octave"] = rng.integers(0, 8, len(k1))
+    k2["octave"] = rng.integers(0, 8, len(k2))
+    n = 400
+    k2["x"][:n], k2["y"][:n], k2["octave"][:n] = k1["x"] + 1, k1["y"] - 1, k1["octave"]
+    bits = np.unpackbits(d1, axis=1)
+    d2[:n] = np.packbits(bits ^ (rng.random(bits.shape) < 0.03), axis=1)
+    t = oracle.tables()
+    # map point i of keyframe 1 carries keypoint i's descriptor and projects onto its partner in keyframe 2, and back
+    pts1 = {"visible": (rng.random(len(k1)) < 0.85).astype(np.uint8), "u": k2["x"][:n].copy(), "v": k2["y"][:n].copy(),
+            "level": k1["octave"].astype(np.int32), "descriptor": d1}
+    pts2 = {"visible": (rng.random(len(k2)) < 0.85).astype(np.uint8),
+            "u": np.concatenate([k1["x"], k2["x"][n:]]).astype(np.float32), "v": np.concatenate([k1["y"], k2["y"][n:]]).astype(np.float32),
+            "level": k2["octave"].astype(np.int32), "descriptor": d2}
+    nf, m12 = oracle.search_by_sim3(k1, d1, k2, d2, GRID, pts1, pts2, 7.5)
+    m1 = np.full(len(k1), -1)
+    m2 = np.full(len(k2), -1)
+    for i in range(len(k1)):
+        if pts1["visible"][i]:
+            bi, best = _py_window_best(k2, d2, None, GRID, pts1, i, 7.5, t["scale"], None, False, None)
+            if best <= 100:
+                m1[i] = bi
+    for i in range(len(k2)):
+        if pts2["visible"][i]:
+            bi, best = _py_window_best(k1, d1, None, GRID, pts2, i, 7.5, t["scale"], None, False, None)
+            if best <= 100:
+                m2[i] = bi
+    want = np.array([m1[i] if m1[i] >= 0 and m2[m1[i]] == i else -1 for i in range(len(k1))], np.int32)
+    assert np.array_equal(m12, want) and nf == (want >= 0).sum() and nf > 100
+    assert ((m1 >= 0) & (want < 0)).any()           # some one-sided choices were dropped
+
+
+def _py_search_for_triangulation(k1, d1, h1, s1, fv1, k2, d2, h2, s2, fv2, F, ep, only_stereo, ori, sf, s2tab):
+    out = np.full(len(k1), -1, np.int32)
+    hist = [[] for _ in range(30)]
+    nm = 0
+    F = np.asarray(F, np.float32).reshape(3, 3)
+    f32 = np.float32
+    for node in sorted(set(fv1) & set(fv2)):
+        for i1 in fv1[node]:
+            if h1[i1] or (only_stereo and not s1[i1]):
+                continue
+            best, bi = 50, -1
+            x1, y1 = f32(k1["x"][i1]), f32(k1["y"][i1])
+            a = f32(f32(f32(x1 * F[0, 0]) + f32(y1 * F[1, 0])) + F[2, 0])
+            b = f32(f32(f32(x1 * F[0, 1]) + f32(y1 * F[1, 1])) + F[2, 1])
+            c = f32(f32(f32(x1 * F[0, 2]) + f32(y1 * F[1, 2])) + F[2, 2])
+            for i2 in fv2[node]:
+                if h2[i2] or (only_stereo and not s2[i2]):
+                    continue
+                d = _ham(d1[i1], d2[i2])
+                if d > 50 or d > best:
+                    continue
+                x2, y2 = f32(k2["x"][i2]), f32(k2["y"][i2])
+                if not s1[i1] and not s2[i2]:
+                    dx, dy = f32(f32(ep[0]) - x2), f32(f32(ep[1]) - y2)
+                    if f32(f32(dx * dx) + f32(dy * dy)) < f32(f32(100) * sf[int(k2["octave"][i2])]):
+                        continue
+                num = f32(f32(f32(a * x2) + f32(b * y2)) + c)
+                den = f32(f32(a * a) + f32(b * b))
+                if den == 0:
+                    continue
+                dsqr = f32(f32(num * num) / den)
+                if float(dsqr) < 3.84 * float(s2tab[int(k2["octave"][i2])]):
+                    best, bi = d, i2
+            if bi >= 0:
+                out[i1] = bi
+                nm += 1
+                if ori:
+                    rot = f32(k1["angle"][i1]) - f32(k2["angle"][bi])
+                    if rot < 0:
+                        rot = f32(rot + f32(360))
+                    bn = int(np.floor(float(f32(rot * f32(1.0 / 30))) + 0.5))
+                    hist[0 if bn == 30 else bn].append(i1)
+    if ori:
+        sizes = [len(h) for h in hist]
+        order = sorted(range(30), key=lambda i: (-sizes[i], i))[:3]
+        keep = [order[0]] if sizes[order[0]] > 0 else []
+        for o_ in order[1:]:
+            if sizes[o_] > 0 and not (f32(sizes[o_]) < f32(0.1) * f32(sizes[order[0]])):
+                keep.append(o_)
+            else:
+                break
+        for bn in range(30):
+            if bn not in keep:
+                for j in hist[bn]:
+                    out[j] = -1
+                    nm -= 1
+    return nm, out
+
+
+def _triangulation_case(rng, n1=600, n2=650, nodes=60):
+    k1, d1, h1, fv1, k2, d2, h2, fv2 = _bow_case(rng, n1, n2, nodes)
+    n = min(n1, n2)
+    # a pure sideways motion: F12 = [t]x with t = (1, 0, 0) up to scale -> epipolar lines are the rows y2 = y1
+    k2["y"][:n] = k1["y"][:n] + rng.choice([0.0, 0.0, 0.5, 1.0, 6.0], n).astype(np.float32)
+    k2["x"][:n] = k1["x"][:n] - rng.uniform(1, 30, n).astype(np.float32)
+    k2["octave"] = rng.integers(0, 8, len(k2))
+    F = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)
+    s1 = (rng.random(n1) < 0.5).astype(np.uint8)
+    s2 = (rng.random(n2) < 0.5).astype(np.uint8)
+    h1 = (rng.random(n1) < 0.3).astype(np.uint8)        # here: keypoints that already hold a map point
+    h2 = (rng.random(n2) < 0.3).astype(np.uint8)
+    ep = (float(k2["x"][5]) + 3.0, float(k2["y"][5]) + 2.0)       # an epipole inside the image, near some keypoints
+    return k1, d1, h1, s1, fv1, k2, d2, h2, s2, fv2, F, ep
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_triangulation_search_against_python_statement(oracle, seed):
+    rng = np.random.default_rng(800 + seed)
+    case = _triangulation_case(rng)
+    t = oracle.tables()
+    for only_stereo, ori in ((False, True), (True, False), (False, False)):
+        nm_o, m_o = oracle.search_for_triangulation(*case, only_stereo, ori)
+        nm_p, m_p = _py_search_for_triangulation(*case, only_stereo, ori, t["scale"], t["sigma2"])
+        assert nm_o == nm_p and np.array_equal(m_o, m_p) and nm_o > (20 if only_stereo else 60)
+    # a keypoint of the second keyframe may serve several of the first (the reference never sets vbMatched2)
+    nm, m = oracle.search_for_triangulation(*case, False, False)
+    vals = m[m >= 0]
+    assert len(vals) == nm

@@ -1688,6 +1688,92 @@ static int grid_candidates(orbx_ctx* c, int N, int Q, float min_x, float min_y, 
     return ORBX_OK;
 }
 
+// One frame's keypoints and Q window queries -> the queries' candidate lists with every distance (what grid_upload +
+// grid_candidates do), with as few copy commands as a call of this size can have: a search of 1000 queries is a few dozen
+// microseconds of kernels, and every copy command between host and device is a dependent step of 5-10 us.  The five
+// small query arrays are read by the kernels where they lie in the page-locked staging area, the counts are written
+// there by the count pass and the offsets read from there by the fill pass; only the three arrays the kernels gather
+// from (keypoints, descriptors, query descriptors) and the two lists go through copies.
+static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, const float* qx, const float* qy,
+                      const float* qr, const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, int Q, float min_x,
+                      float min_y, float inv_w, float inv_h, std::vector<int32_t>& off, std::vector<int32_t>& idx,
+                      std::vector<uint16_t>& dist)
+{
+    static const bool plain = getenv("ORBX_NO_ZERO_COPY") != nullptr;
+    if (plain || Q <= 0 || N <= 0) {
+        int rc = grid_upload(c, kps, desc, N, qx, qy, qr, qmin, qmax, qdesc, Q);
+        if (rc != ORBX_OK) return rc;
+        return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    }
+    if (!kps || !desc || !qx || !qy || !qr || !qmin || !qmax || !qdesc) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    HIPCHECK(c, hipSetDevice(c->device));
+    HIPCHECK(c, finish(c));
+    const size_t q = (size_t)Q;
+    // keypoints | descriptors | query descriptors: one block on the device, one copy
+    const size_t kb = ((size_t)N * sizeof(orbx_keypoint) + 63) & ~(size_t)63, db = (size_t)N * 32, qdb = q * 32;
+    HIPCHECK(c, c->gq[0].ensure(kb + db + qdb));
+    {
+        const size_t need_s = (size_t)(kFrameGridCells + 1) * 4, need_l = (size_t)N * 4;
+        HIPCHECK(c, c->grid_start.ensure(need_s));
+        HIPCHECK(c, c->grid_list.ensure(need_l));
+    }
+    // the staging block of this call: the device block's image, then the arrays the kernels read and write in place
+    size_t o;
+    const size_t qb = (q * 4 + 63) & ~(size_t)63, ob = ((q + 1) * 4 + 63) & ~(size_t)63;
+    HIPCHECK(c, arena_reserve(c, kb + db + qdb + 6 * qb + ob, &o));
+    std::memcpy(c->pin + o, kps, (size_t)N * sizeof(orbx_keypoint));
+    std::memcpy(c->pin + o + kb, desc, db);
+    std::memcpy(c->pin + o + kb + db, qdesc, qdb);
+    HIPCHECK(c, hipMemcpyAsync(c->gq[0].p, c->pin + o, kb + db + qdb, hipMemcpyHostToDevice, c->stream));
+    uint8_t* const dblk = c->gq[0].as<uint8_t>();
+    const uint32_t* const d_desc = reinterpret_cast<const uint32_t*>(dblk + kb);
+    const uint32_t* const d_qdesc = reinterpret_cast<const uint32_t*>(dblk + kb + db);
+    uint8_t* blk = c->pin + o + kb + db + qdb;
+    float* z_qx = reinterpret_cast<float*>(blk);
+    float* z_qy = reinterpret_cast<float*>(blk + qb);
+    float* z_qr = reinterpret_cast<float*>(blk + 2 * qb);
+    int32_t* z_qmin = reinterpret_cast<int32_t*>(blk + 3 * qb);
+    int32_t* z_qmax = reinterpret_cast<int32_t*>(blk + 4 * qb);
+    int32_t* z_cnt = reinterpret_cast<int32_t*>(blk + 5 * qb);
+    int32_t* z_off = reinterpret_cast<int32_t*>(blk + 6 * qb);
+    std::memcpy(z_qx, qx, q * 4);
+    std::memcpy(z_qy, qy, q * 4);
+    std::memcpy(z_qr, qr, q * 4);
+    std::memcpy(z_qmin, qmin, q * 4);
+    std::memcpy(z_qmax, qmax, q * 4);
+    const orbx_keypoint* d_kps = c->gq[0].as<orbx_keypoint>();
+    launch_grid_build(d_kps, nullptr, N, N, 1, min_x, min_y, inv_w, inv_h, c->grid_start.as<int>(), c->grid_list.as<int>(), c->stream);
+    launch_grid_lists(d_kps, nullptr, c->grid_start.as<int>(), c->grid_list.as<int>(), N, 1, z_qx, z_qy, z_qr, z_qmin, z_qmax,
+                      nullptr, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, z_cnt, nullptr, nullptr, nullptr, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    HIPCHECK(c, hipStreamSynchronize(c->stream));      // not finish(): the staging block stays reserved
+    off.assign(q + 1, 0);
+    long long sum = 0;
+    for (int k = 0; k < Q; k++) { off[k] = (int32_t)sum; sum += z_cnt[k]; }
+    if (sum > 0x7fffffffLL) { (void)finish(c); return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates"); }
+    off[Q] = (int32_t)sum;
+    idx.assign((size_t)sum, 0);
+    dist.assign((size_t)sum, 0);
+    if (sum == 0) { HIPCHECK(c, finish(c)); return ORBX_OK; }
+    std::memcpy(z_off, off.data(), (q + 1) * 4);
+    // the lists: indices | distances in one block, one copy back
+    HIPCHECK(c, c->gq[11].ensure((size_t)sum * 6));
+    int32_t* const d_idx = c->gq[11].as<int32_t>();
+    uint16_t* const d_dist = reinterpret_cast<uint16_t*>(c->gq[11].as<uint8_t>() + (size_t)sum * 4);
+    launch_grid_lists(d_kps, d_desc, c->grid_start.as<int>(), c->grid_list.as<int>(), N, 1, z_qx, z_qy, z_qr, z_qmin, z_qmax,
+                      d_qdesc, nullptr, Q, Q, min_x, min_y, inv_w, inv_h, nullptr, z_off, d_idx, d_dist, c->stream);
+    HIPCHECK(c, hipGetLastError());
+    // (a reservation that has to enlarge the staging area drains the stream first: the fill pass is done with the block by then)
+    size_t oo;
+    HIPCHECK(c, arena_reserve(c, (size_t)sum * 6, &oo));
+    HIPCHECK(c, hipMemcpyAsync(c->pin + oo, c->gq[11].p, (size_t)sum * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, hipStreamSynchronize(c->stream));
+    std::memcpy(idx.data(), c->pin + oo, (size_t)sum * 4);
+    std::memcpy(dist.data(), c->pin + oo + (size_t)sum * 4, (size_t)sum * 2);
+    HIPCHECK(c, finish(c));
+    return ORBX_OK;
+}
+
 // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1723-1764
 static void three_maxima(const std::vector<int32_t>* histo, int L, int& ind1, int& ind2, int& ind3)
 {
@@ -1731,11 +1817,10 @@ int orbx_search_for_initialization(orbx_ctx* c, const orbx_keypoint* k1, const u
         ql[q] = k1[i].octave;
         std::memcpy(&qd[(size_t)q * 8], d1 + (size_t)i * 8, 32);
     }
-    int rc = grid_upload(c, k2, d2, n2, qx.data(), qy.data(), qr.data(), ql.data(), ql.data(), qd.data(), Q);
-    if (rc != ORBX_OK) return rc;
     std::vector<int32_t> off, idx;
     std::vector<uint16_t> dist;
-    rc = grid_candidates(c, n2, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    int rc = grid_lists(c, k2, d2, n2, qx.data(), qy.data(), qr.data(), ql.data(), ql.data(), qd.data(), Q, min_x, min_y, inv_w,
+                        inv_h, off, idx, dist);
     if (rc != ORBX_OK) return rc;
 
     int nm = 0;
@@ -1825,9 +1910,8 @@ static int projection_queries(orbx_ctx* c, const orbx_keypoint* kps, const uint3
         qmax[q] = mp_level[i];
         std::memcpy(&qd[(size_t)q * 8], mp_desc + (size_t)i * 8, 32);
     }
-    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
-    if (rc != ORBX_OK) return rc;
-    return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    return grid_lists(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q, min_x, min_y, inv_w,
+                      inv_h, off, idx, dist);
 }
 
 // One map point against its candidate list: the scan and the accept step shared by SearchByProjection
@@ -2142,11 +2226,10 @@ static int projected_points_search(orbx_ctx* c, const orbx_keypoint* kps, const 
         else { qmin[q] = o - 1; qmax[q] = o + 1; }
         std::memcpy(&qd[(size_t)q * 8], lp_desc + (size_t)i * 8, 32);
     }
-    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
-    if (rc != ORBX_OK) return rc;
     std::vector<int32_t> off, idx;
     std::vector<uint16_t> dist;
-    rc = grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
+    int rc = grid_lists(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q, min_x, min_y,
+                        inv_w, inv_h, off, idx, dist);
     if (rc != ORBX_OK) return rc;
 
     int nm = 0;
@@ -2258,9 +2341,8 @@ static int window_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* d
         qmax[q] = level[i];
         std::memcpy(&qd[(size_t)q * 8], mp_desc + (size_t)i * 8, 32);
     }
-    int rc = grid_upload(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q);
-    if (rc != ORBX_OK) return rc;
-    return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, wl.off, wl.idx, wl.dist);
+    return grid_lists(c, kps, desc, N, qx.data(), qy.data(), qr.data(), qmin.data(), qmax.data(), qd.data(), Q, min_x, min_y, inv_w,
+                      inv_h, wl.off, wl.idx, wl.dist);
 }
 
 int orbx_search_by_projection_sim3(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, float min_x, float min_y,

@@ -134,6 +134,11 @@ struct UndistortModel {
 void launch_undistort(const orbx_keypoint* d_in, const int32_t* d_n, int n_fixed, int cap, int nframes,
                       const UndistortModel& m, orbx_keypoint* d_out, hipStream_t s);
 
+void launch_grid_lists(const orbx_keypoint* d_kps, const uint32_t* d_desc, const int* d_cell_start, const int* d_cell_list,
+                       int stride, int nbatch, const float* qx, const float* qy, const float* qr, const int32_t* qmin,
+                       const int32_t* qmax, const uint32_t* qdesc, const int32_t* d_nq, int Q, int q_stride, float minX, float minY,
+                       float invW, float invH, int32_t* ncand, const int32_t* cand_off, int32_t* cand_idx, uint16_t* cand_dist,
+                       hipStream_t s);
 void launch_grid_build(const orbx_keypoint* d_kps, const int32_t* d_n, int N, int stride, int nbatch, float minX,
                        float minY, float invW, float invH, int* d_cell_start, int* d_cell_list, hipStream_t s);
 void launch_grid_search(const orbx_keypoint* d_kps, const uint32_t* d_desc, const int* d_cell_start,

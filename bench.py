@@ -749,6 +749,9 @@ def main():
             legs["with_transfer_" + label] = {"frames_per_s": round(B / dt_, 1), "ms_per_batch": round(dt_ * 1e3, 3),
                                               "what": "orbx_extract_batch on %s host buffers: upload, kernels, download, "
                                                       "synchronise" % ("page-locked" if pinned else "pageable")}
+        # the searches a tracker runs once per frame, as whole-routine calls (host arrays in and out)
+        from search_leg import measure as measure_search_calls
+        legs["search_calls"] = measure_search_calls(ex, wl.host[0])
         ex.set_stream(stream.cuda_stream)
         out["legs"] = legs
 

@@ -1597,6 +1597,11 @@ int orbx_grid_search(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc
     return ORBX_OK;
 }
 
+static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, const float* qx, const float* qy,
+                      const float* qr, const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, int Q, float min_x,
+                      float min_y, float inv_w, float inv_h, std::vector<int32_t>& off, std::vector<int32_t>& idx,
+                      std::vector<uint16_t>& dist);
+
 int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float min_x, float min_y, float inv_w, float inv_h,
                           const float* qx, const float* qy, const float* qr, const int32_t* qmin, const int32_t* qmax, int Q,
                           int32_t* cand_off, int32_t* cand_idx, int cap, int* total)
@@ -1606,6 +1611,19 @@ int orbx_features_in_area(orbx_ctx* c, const orbx_keypoint* kps, int N, float mi
     if (N < 0 || Q < 0 || !cand_off) return fail(c, ORBX_ERR_INVALID, "bad arguments");
     cand_off[0] = 0;
     if (Q == 0) return ORBX_OK;
+    if (N > 0 && !getenv("ORBX_NO_ZERO_COPY")) {
+        // the lists by 16 lanes per query, one upload block, small arrays read in place (as the whole-routine searches do)
+        std::vector<int32_t> off, idx;
+        std::vector<uint16_t> none;
+        int rc = grid_lists(c, kps, nullptr, N, qx, qy, qr, qmin, qmax, nullptr, Q, min_x, min_y, inv_w, inv_h, off, idx, none);
+        if (rc != ORBX_OK) return rc;
+        std::memcpy(cand_off, off.data(), ((size_t)Q + 1) * 4);
+        *total = off[Q];
+        if (off[Q] == 0) return ORBX_OK;
+        if (!cand_idx || cap < off[Q]) return fail(c, ORBX_ERR_CAPACITY, "candidate buffer too small");
+        std::memcpy(cand_idx, idx.data(), (size_t)off[Q] * 4);
+        return ORBX_OK;
+    }
     int rc = grid_upload(c, kps, nullptr, N, qx, qy, qr, qmin, qmax, nullptr, Q);
     if (rc != ORBX_OK) return rc;
     const int stride = N > 0 ? N : 1;
@@ -1705,12 +1723,13 @@ static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* des
         if (rc != ORBX_OK) return rc;
         return grid_candidates(c, N, Q, min_x, min_y, inv_w, inv_h, off, idx, dist);
     }
-    if (!kps || !desc || !qx || !qy || !qr || !qmin || !qmax || !qdesc) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    if (!kps || !qx || !qy || !qr || !qmin || !qmax || (desc != nullptr) != (qdesc != nullptr)) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    const bool with_dist = desc != nullptr;      // without descriptors: the lists alone (Frame::GetFeaturesInArea)
     HIPCHECK(c, hipSetDevice(c->device));
     HIPCHECK(c, finish(c));
     const size_t q = (size_t)Q;
     // keypoints | descriptors | query descriptors: one block on the device, one copy
-    const size_t kb = ((size_t)N * sizeof(orbx_keypoint) + 63) & ~(size_t)63, db = (size_t)N * 32, qdb = q * 32;
+    const size_t kb = ((size_t)N * sizeof(orbx_keypoint) + 63) & ~(size_t)63, db = with_dist ? (size_t)N * 32 : 0, qdb = with_dist ? q * 32 : 0;
     HIPCHECK(c, c->gq[0].ensure(kb + db + qdb));
     {
         const size_t need_s = (size_t)(kFrameGridCells + 1) * 4, need_l = (size_t)N * 4;
@@ -1722,12 +1741,14 @@ static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* des
     const size_t qb = (q * 4 + 63) & ~(size_t)63, ob = ((q + 1) * 4 + 63) & ~(size_t)63;
     HIPCHECK(c, arena_reserve(c, kb + db + qdb + 6 * qb + ob, &o));
     std::memcpy(c->pin + o, kps, (size_t)N * sizeof(orbx_keypoint));
-    std::memcpy(c->pin + o + kb, desc, db);
-    std::memcpy(c->pin + o + kb + db, qdesc, qdb);
+    if (with_dist) {
+        std::memcpy(c->pin + o + kb, desc, db);
+        std::memcpy(c->pin + o + kb + db, qdesc, qdb);
+    }
     HIPCHECK(c, hipMemcpyAsync(c->gq[0].p, c->pin + o, kb + db + qdb, hipMemcpyHostToDevice, c->stream));
     uint8_t* const dblk = c->gq[0].as<uint8_t>();
-    const uint32_t* const d_desc = reinterpret_cast<const uint32_t*>(dblk + kb);
-    const uint32_t* const d_qdesc = reinterpret_cast<const uint32_t*>(dblk + kb + db);
+    const uint32_t* const d_desc = with_dist ? reinterpret_cast<const uint32_t*>(dblk + kb) : nullptr;
+    const uint32_t* const d_qdesc = with_dist ? reinterpret_cast<const uint32_t*>(dblk + kb + db) : nullptr;
     uint8_t* blk = c->pin + o + kb + db + qdb;
     float* z_qx = reinterpret_cast<float*>(blk);
     float* z_qy = reinterpret_cast<float*>(blk + qb);
@@ -1753,11 +1774,12 @@ static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* des
     if (sum > 0x7fffffffLL) { (void)finish(c); return fail(c, ORBX_ERR_UNSUPPORTED, "more than 2^31 candidates"); }
     off[Q] = (int32_t)sum;
     idx.assign((size_t)sum, 0);
-    dist.assign((size_t)sum, 0);
+    dist.assign(with_dist ? (size_t)sum : 0, 0);
     if (sum == 0) { HIPCHECK(c, finish(c)); return ORBX_OK; }
     std::memcpy(z_off, off.data(), (q + 1) * 4);
     // the lists: indices | distances in one block, one copy back
-    HIPCHECK(c, c->gq[11].ensure((size_t)sum * 6));
+    const size_t lb = (size_t)sum * (with_dist ? 6 : 4);
+    HIPCHECK(c, c->gq[11].ensure(lb));
     int32_t* const d_idx = c->gq[11].as<int32_t>();
     uint16_t* const d_dist = reinterpret_cast<uint16_t*>(c->gq[11].as<uint8_t>() + (size_t)sum * 4);
     launch_grid_lists(d_kps, d_desc, c->grid_start.as<int>(), c->grid_list.as<int>(), N, 1, z_qx, z_qy, z_qr, z_qmin, z_qmax,
@@ -1765,11 +1787,11 @@ static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* des
     HIPCHECK(c, hipGetLastError());
     // (a reservation that has to enlarge the staging area drains the stream first: the fill pass is done with the block by then)
     size_t oo;
-    HIPCHECK(c, arena_reserve(c, (size_t)sum * 6, &oo));
-    HIPCHECK(c, hipMemcpyAsync(c->pin + oo, c->gq[11].p, (size_t)sum * 6, hipMemcpyDeviceToHost, c->stream));
+    HIPCHECK(c, arena_reserve(c, lb, &oo));
+    HIPCHECK(c, hipMemcpyAsync(c->pin + oo, c->gq[11].p, lb, hipMemcpyDeviceToHost, c->stream));
     HIPCHECK(c, hipStreamSynchronize(c->stream));
     std::memcpy(idx.data(), c->pin + oo, (size_t)sum * 4);
-    std::memcpy(dist.data(), c->pin + oo + (size_t)sum * 4, (size_t)sum * 2);
+    if (with_dist) std::memcpy(dist.data(), c->pin + oo + (size_t)sum * 4, (size_t)sum * 2);
     HIPCHECK(c, finish(c));
     return ORBX_OK;
 }

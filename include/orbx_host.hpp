@@ -562,6 +562,28 @@ public:
         return nmatches;
     }
 
+    // SearchByProjection(CurrentFrame, pKF, sAlreadyFound, th, ORBdist), src/ORBmatcher.cc:1595-1721 (relocalisation), from the
+    // projected points on: `kf` holds, per keypoint of the keyframe, visible / u / v, octave = the predicted level, angle =
+    // pKF->mvKeysUn[i].angle, the map point's descriptor and Observations (invzc is not read).  frame_obs[i2] >= 0 = the
+    // keypoint of the current frame holds a map point.
+    int SearchByProjection(const std::vector<orbx_keypoint>& keysUn, const uint8_t* desc, const FrameGrid& grid,
+                           const LastFramePoints& kf, float th, int ORBdist, std::vector<int32_t>& frame_obs,
+                           std::vector<int32_t>& frame_match)
+    {
+        const size_t N = keysUn.size(), M = kf.visible.size();
+        if (frame_obs.size() != N || frame_match.size() != N || kf.u.size() != M || kf.v.size() != M || kf.angle.size() != M ||
+            kf.octave.size() != M || kf.Observations.size() != M || kf.descriptors.size() != 32 * M)
+            throw std::invalid_argument("array lengths do not agree");
+        int nmatches = 0;
+        check(orbx_search_by_projection_keyframe(ex_.context(), keysUn.data(), reinterpret_cast<const uint32_t*>(desc), (int)N,
+                                                 grid.mnMinX, grid.mnMinY, grid.mfGridElementWidthInv, grid.mfGridElementHeightInv,
+                                                 kf.visible.data(), kf.u.data(), kf.v.data(), kf.octave.data(), kf.angle.data(),
+                                                 reinterpret_cast<const uint32_t*>(kf.descriptors.data()), kf.Observations.data(),
+                                                 (int)M, th, ORBdist, mbCheckOrientation ? 1 : 0, frame_obs.data(),
+                                                 frame_match.data(), &nmatches));
+        return nmatches;
+    }
+
     // SearchByProjection(pKF, Scw, vpPoints, vpMatched, th), src/ORBmatcher.cc:406-518, from the projected points on.
     // kfMatched[idx] >= 0 = vpMatched[idx] is set (in/out); kfMatch[idx] = the point of `pts` this call stored there.
     int SearchByProjection(const std::vector<orbx_keypoint>& kfKeysUn, const uint8_t* kfDesc, const FrameGrid& grid,

@@ -476,3 +476,91 @@ def test_triangulation_search(matcher, oracle, seed):
         nm_g, m_g = m.SearchForTriangulation(*case, only_stereo)
         nm_o, m_o = oracle.search_for_triangulation(*case, only_stereo, ori)
         assert nm_g == nm_o and np.array_equal(m_g, m_o) and nm_g > (60 if only_stereo else 200)
+
+
+def test_cpp_matcher_calls(oracle, euroc_left, euroc_right, tmp_path):
+    """orbx::ORBmatcher from C++ (tests/cpp/matcher_calls.cpp): SearchByBoW (both forms), SearchForTriangulation,
+    SearchByProjection with a Sim3, both Fuse searches, SearchBySim3, the relocalisation search and the budgeted
+    local-map search on the EuRoC pair, every output array against the CPU restatement fed the same derived inputs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "cpp", "matcher_calls")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "matcher_calls"])
+    raw, out = tmp_path / "pair.raw", tmp_path / "calls.bin"
+    np.stack([euroc_left, euroc_right]).tofile(raw)
+    p = subprocess.run([exe, str(raw), "752", "480", str(out)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+    assert p.returncode == 0, p.stderr.decode()
+    data = np.frombuffer(out.read_bytes(), np.int32)
+    blocks, pos = [], 0
+    while pos < len(data):
+        n = int(data[pos])
+        blocks.append(data[pos + 1:pos + 1 + n])
+        pos += 1 + n
+    it = iter(blocks)
+    k1, d1 = oracle.extract(euroc_left)
+    k2, d2 = oracle.extract(euroc_right)
+    n1, n2 = len(k1), len(k2)
+    assert next(it).tolist() == [n1, n2]
+    grid = (0.0, 0.0, float(np.float32(64) / np.float32(752)), float(np.float32(48) / np.float32(480)))
+
+    def fv_of(d):
+        bits = np.unpackbits(d, axis=1)
+        nd = (bits[:, 0:64].sum(1) > 32).astype(np.int64) * 4 + (bits[:, 64:128].sum(1) > 32) * 2 + (bits[:, 128:192].sum(1) > 32)
+        return {int(v): np.nonzero(nd == v)[0].tolist() for v in np.unique(nd)}
+
+    fv1, fv2 = fv_of(d1), fv_of(d2)
+    i1, i2 = np.arange(n1), np.arange(n2)
+    has1, has2 = (i1 % 9 != 0).astype(np.uint8), (i2 % 7 != 0).astype(np.uint8)
+    held1, held2 = (i1 % 3 == 0).astype(np.uint8), (i2 % 4 == 0).astype(np.uint8)
+    st1, st2 = (i1 % 2).astype(np.uint8), ((i2 // 2) % 2).astype(np.uint8)
+
+    def expect(nm, *arrays):
+        assert next(it).tolist() == [nm]
+        for a in arrays:
+            assert np.array_equal(next(it), a)
+
+    nm, m = oracle.search_by_bow_frame(k1, d1, has1, fv1, k2, d2, fv2, 0.7, True)
+    assert nm > 100
+    expect(nm, m)
+    nm, m = oracle.search_by_bow_keyframes(k1, d1, has1, fv1, k2, d2, has2, fv2, 0.7, True)
+    expect(nm, m)
+    F = np.array([0, 0, 0, 0, 0, -1, 0, 1, 0], np.float32)
+    nm, m = oracle.search_for_triangulation(k1, d1, held1, st1, fv1, k2, d2, held2, st2, fv2, F, (752 * 0.5 + 0.5, 480 * 0.5), False, True)
+    expect(nm, m)
+
+    def pts_of(k, d):
+        n = len(k)
+        return {"visible": (np.arange(n) % 5 != 0).astype(np.uint8), "u": k["x"].copy(), "v": k["y"].copy(),
+                "ur": (k["x"] - np.float32(10)).astype(np.float32), "level": k["octave"].astype(np.int32), "descriptor": d}
+    p1, p2 = pts_of(k1, d1), pts_of(k2, d2)
+    matched = np.where(i2 % 4 == 0, 1, -1).astype(np.int32)
+    match = np.full(n2, -1, np.int32)
+    nm = oracle.search_by_projection_sim3(k2, d2, grid, p1, 10, matched, match)
+    expect(nm, matched, match)
+    ur2 = np.where(i2 % 2 == 1, k2["x"] - np.float32(10), np.float32(-1)).astype(np.float32)
+    nf, bi, bd = oracle.fuse_search(k2, d2, ur2, grid, p1, 3.0, True)
+    expect(nf, bi, bd)
+    nf, bi, bd = oracle.fuse_search(k2, d2, None, grid, p1, 4.0, False)
+    expect(nf, bi, bd)
+    nf, m = oracle.search_by_sim3(k1, d1, k2, d2, grid, p1, p2, 7.5)
+    assert nf > 100
+    expect(nf, m)
+    kf = {"visible": p1["visible"], "u": p1["u"], "v": p1["v"], "level": p1["level"], "angle": k1["angle"].astype(np.float32),
+          "descriptor": d1, "Observations": np.ones(n1, np.int32)}
+    fobs = np.where(i2 % 6 == 0, 0, -1).astype(np.int32)
+    fmatch = np.full(n2, -1, np.int32)
+    nm = oracle.search_by_projection_keyframe(k2, d2, grid, kf, 10.0, 64, True, fobs, fmatch)
+    expect(nm, fobs, fmatch)
+    mp = {"mbTrackInView": np.ones(n1, np.uint8), "isBad": np.zeros(n1, np.uint8), "mTrackProjX": k1["x"].copy(),
+          "mTrackProjY": k1["y"].copy(), "mTrackProjXR": (k1["x"] - np.float32(10)).astype(np.float32),
+          "mnTrackScaleLevel": k1["octave"].astype(np.int32),
+          "mTrackViewCos": np.where(i1 % 2 == 1, np.float32(0.9995), np.float32(0.9)).astype(np.float32),
+          "Observations": np.ones(n1, np.int32), "descriptor": d1}
+    o2, m2, s2 = (np.full(n2, -1, np.int32) for _ in range(3))
+    nm, stop = oracle.search_by_projection_budget(k2, d2, ur2, grid, mp, 3.0, 0.7, 1e12, o2, m2, s2)
+    expect(nm)
+    assert next(it).tolist() == [stop] and stop == n1
+    assert np.array_equal(next(it), m2) and np.array_equal(next(it), s2)
+    assert next(it, None) is None

@@ -31,20 +31,10 @@ __device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c)
     return max(min(a, b), min(max(a, b), c));
 }
 
-// (written as instructions: the compiler shares min(a, b) between a minimum and a median of the same three values
-// and then needs three instructions for the two)
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ uint32_t umed3i(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// (the minimum is written b-and-c first: min(a, b) would be shared with the median of the same three values, and the
+// two would then take three instructions instead of v_min3_u32 + v_med3_u32.  Not as inline assembly: the compiler
+// does not count the wait states between a matrix instruction and an assembly statement that reads its result.)
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
 
 // keep the two smallest keys seen so far (best <= second)
 __device__ __forceinline__ void push_key(uint32_t& best, uint32_t& second, uint32_t key)
@@ -218,9 +208,14 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
             acc[qt][4 * g] = c.x; acc[qt][4 * g + 1] = c.y; acc[qt][4 * g + 2] = c.z; acc[qt][4 * g + 3] = c.w;
         }
     }
+    // the fragment of k-step s + 1 is on its way from LDS while the matrix instructions of step s run
+    v4i_t a_cur = a_frag[lane], a_nxt = a_cur;
 #pragma unroll
     for (int s = 0; s < 4; s++) {
-        const v4i_t a = a_frag[s * 64 + lane];
+        if (s < 3) a_nxt = a_frag[(s + 1) * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        const v4i_t a = a_cur;
+        a_cur = a_nxt;
         const v8i_t a8 = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 #pragma unroll
         for (int qt = 0; qt < QT; qt++) {
@@ -247,13 +242,13 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
 #pragma unroll
         for (int i = 0; i < 5; i++) {
             m[i] = umin3(k[3 * i], k[3 * i + 1], k[3 * i + 2]);
-            d[i] = umed3i(k[3 * i], k[3 * i + 1], k[3 * i + 2]);
+            d[i] = umed3(k[3 * i], k[3 * i + 1], k[3 * i + 2]);
         }
         m[5] = best[qt];
         d[5] = second[qt];
         push_key(m[5], d[5], k[15]);
-        const uint32_t ma = umin3(m[0], m[1], m[2]), da = min(umed3i(m[0], m[1], m[2]), umin3(d[0], d[1], d[2]));
-        const uint32_t mb = umin3(m[3], m[4], m[5]), db = min(umed3i(m[3], m[4], m[5]), umin3(d[3], d[4], d[5]));
+        const uint32_t ma = umin3(m[0], m[1], m[2]), da = min(umed3(m[0], m[1], m[2]), umin3(d[0], d[1], d[2]));
+        const uint32_t mb = umin3(m[3], m[4], m[5]), db = min(umed3(m[3], m[4], m[5]), umin3(d[3], d[4], d[5]));
         best[qt] = min(ma, mb);
         second[qt] = umin3(max(ma, mb), da, db);
     }

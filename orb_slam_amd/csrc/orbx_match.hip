@@ -191,10 +191,9 @@ __device__ __forceinline__ v4i_t expand32_fp4(const uint32_t* __restrict__ lut, 
 
 // c_rows: the start values of the tile's 32 rows (one set of reads serves every accumulator: the first matrix
 // instruction of the second accumulator takes the first one's start registers as its C operand)
-template <int QT, bool kPartial>
+template <int QT>
 __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, const float* __restrict__ c_rows, int lane, int half,
-                                          const v4i_t (&bq)[QT][4], int valid_rows, uint32_t (&best)[QT],
-                                          uint32_t (&second)[QT])
+                                          const v4i_t (&bq)[QT][4], uint32_t (&best)[QT], uint32_t (&second)[QT])
 {
     constexpr int kScaleA = 0x7f7f7f7f;                         // E8M0 2^0
     constexpr int kScaleB = (int)0x8c8c8c8cu;                   // E8M0 2^13: twice the unit of the distance field
@@ -236,7 +235,6 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
             // the vector whatever the index)
             const float f = acc[qt][e];
             k[e] = __float_as_uint(f);
-            if (kPartial) k[e] = 8 * (e >> 2) + 4 * half + (e & 3) < valid_rows ? k[e] : 0xffffffffu;
         }
         uint32_t m[6], d[6];
 #pragma unroll
@@ -275,15 +273,20 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
         s_lut[threadIdx.x] = v;
     }
     constexpr uint32_t kRowBase = kFp4Base + (256u << kFp4RunBits);
-    if (threadIdx.x < 32 * NT) s_c[0][threadIdx.x] = kRowBase + threadIdx.x;    // the first group's rows: positions 0.. of the first run
-    __syncthreads();
+    // Rows past the end of the sweep's train descriptors (the last tile of a sweep may be short; its fragments repeat
+    // the last descriptor) start kFp4Past distance units higher: above every key of a real row and, once the queries'
+    // own bit counts are restored, at a distance above 256, which is read as "none".
+    constexpr uint32_t kFp4Past = 300u << kFp4RunBits;
     const int nQ = nq ? min(nq[b], q_stride) : Q;
     const int nT = nt ? min(nt[b], T) : T;     // T is the per-batch maximum
+    const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
+    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
+    // the first group's rows: positions 0.. of the first run
+    if (threadIdx.x < 32 * NT) s_c[0][threadIdx.x] = kRowBase + threadIdx.x + (j0 + (int)threadIdx.x < j1 ? 0u : kFp4Past);
+    __syncthreads();
     const int q0 = (blockIdx.x * kFp4Waves + wave) * (32 * QT);
     if (blockIdx.x * kFp4Waves * (32 * QT) >= nQ) return;          // whole workgroup past the queries
     const bool active = q0 < nQ;                                          // idle wavefronts still help expanding
-    const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
-    const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
 
     // the first tile's train dwords are on their way while the queries are expanded
     const uint32_t* tp = t + (size_t)b * t_stride * 8 + 2 * wave + half;
@@ -342,7 +345,9 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
             s_a[buf][k][wave * 64 + lane] = expand32_fp4(s_lut, mn[k]);
         }
         const int cn = cb == 2 ? 0 : cb + 1;
-        if (threadIdx.x < 32 * NT) s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 * NT - j0) & kRunMask) + (int)threadIdx.x);
+        if (threadIdx.x < 32 * NT)
+            s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 * NT - j0) & kRunMask) + (int)threadIdx.x) +
+                                   (j + 32 * NT + (int)threadIdx.x < j1 ? 0u : kFp4Past);
 #pragma unroll
         for (int k = 0; k < NT; k++)
             if (j + 32 * (NT + k) < j1) mn[k] = tp[8 * (size_t)min(j + 32 * (NT + k) + r, j1 - 1)];
@@ -351,8 +356,7 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
             const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
 #pragma unroll
             for (int k = 0; k < NT; k++) {
-                if (j + 32 * (k + 1) <= j1) fp4_sweep<QT, false>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, 32, best, second);
-                else if (j + 32 * k < j1) fp4_sweep<QT, true>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, j1 - j - 32 * k, best, second);
+                if (j + 32 * k < j1) fp4_sweep<QT>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, best, second);
             }
             if (((j + 32 * NT - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
         }
@@ -370,8 +374,10 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
         const int qi = q0 + 32 * qt + r;
         if (half != 0 || qi >= nQ) continue;
         const uint32_t fix = (uint32_t)(pa[qt] - 256) << 22;
-        const uint32_t kb = gbest[qt] == 0xffffffffu ? kKeyNone : gbest[qt] + fix;
-        const uint32_t ks = gsecond[qt] == 0xffffffffu ? kKeyNone : gsecond[qt] + fix;
+        uint32_t kb = gbest[qt] == 0xffffffffu ? kKeyNone : gbest[qt] + fix;
+        uint32_t ks = gsecond[qt] == 0xffffffffu ? kKeyNone : gsecond[qt] + fix;
+        if ((kb >> 22) >= 256u) kb = kKeyNone;                  // a row past the end, or all 256 bits different
+        if ((ks >> 22) >= 256u) ks = kKeyNone;
         const size_t o = (size_t)b * q_stride + qi;
         if (tsplit == 1) {
             best_idx[o] = (kb >> 22) >= 256u ? -1 : (int32_t)(kb & 0x3FFFFFu);

@@ -113,7 +113,7 @@ struct orbx_ctx {
     // staging for the host-buffer entry points
     DevBuf in, out_kps, out_desc, out_n;
     // scratch for matching
-    DevBuf partial, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
+    DevBuf partial, match_expand, m0, m1, m2, m3, m4, m5, m6, m7, m8, m9;
     DevBuf grid_start, grid_list, gq[12], stereo_listed, stereo_rows;
 
     int last_nframes = 0;
@@ -706,7 +706,7 @@ void orbx_destroy(orbx_ctx* c)
     (void)finish(c);
     DevBuf* bufs[] = {&c->raw_cells0, &c->raw_ytab2, &c->xtab, &c->ytab, &c->xtab4, &c->ytab2, &c->fast_cells, &c->pyr, &c->blur, &c->cell_cand, &c->cell_count, &c->cell_off, &c->key_xy,
                       &c->key_resp, &c->key_node, &c->kp_stage, &c->level_count, &c->level_ncand, &c->qt_scratch, &c->qt_counts, &c->in, &c->out_kps,
-                      &c->out_desc, &c->out_n, &c->partial, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
+                      &c->out_desc, &c->out_n, &c->partial, &c->match_expand, &c->m0, &c->m1, &c->m2, &c->m3, &c->m4, &c->m5, &c->m6,
                       &c->m7, &c->m8, &c->m9, &c->grid_start, &c->grid_list, &c->gq[0], &c->gq[1], &c->gq[2],
                       &c->gq[3], &c->gq[4], &c->gq[5], &c->gq[6], &c->gq[7], &c->gq[8], &c->gq[9], &c->gq[10], &c->gq[11],
                       &c->stereo_listed, &c->stereo_rows};
@@ -1113,8 +1113,14 @@ int orbx_match_bruteforce_device(orbx_ctx* c, const uint32_t* d_q, int Q, int q_
             HIPCHECK(c, c->partial.ensure(need));
         }
     }
+    // many tiles of queries against one train set: the set is expanded to its matrix form once, in memory
+    const size_t expand = match_expand_bytes(q_stride, T, t_stride, nbatch);
+    if (expand > c->match_expand.bytes) {
+        HIPCHECK(c, finish(c));
+        HIPCHECK(c, c->match_expand.ensure(expand));
+    }
     launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->partial.as<uint32_t>(),
-                            d_best_idx, d_best_dist, d_second_dist, c->stream);
+                            expand ? c->match_expand.as<uint32_t>() : nullptr, d_best_idx, d_best_dist, d_second_dist, c->stream);
     HIPCHECK(c, hipGetLastError());
     return ORBX_OK;
 }
@@ -1139,7 +1145,7 @@ int orbx_match_bruteforce_device_static(orbx_ctx* c, const uint32_t* d_q, int Q,
     if (tsplit > 1 && per_split * (size_t)tsplit > kMatchStaticScratchBytes)
         tsplit = (int)std::max<size_t>(1, kMatchStaticScratchBytes / per_split);
     // every slot k_match_merge reads is written by this call's sweep first: nothing to clear
-    launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->static_scratch,
+    launch_match_bruteforce(d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt, nbatch, tsplit, c->static_scratch, nullptr,
                             d_best_idx, d_best_dist, d_second_dist, c->stream);
     HIPCHECK(c, hipGetLastError());
     return ORBX_OK;

@@ -85,8 +85,9 @@ void launch_orient_desc(const FrameGeom& g, const uint8_t* pyr, const uint8_t* b
 // matching (orbx_match.hip)
 void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
                              const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
-                             int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
+                             int tsplit, uint32_t* d_partial, uint32_t* d_expand, int32_t* d_best_idx, int32_t* d_best_dist,
                              int32_t* d_second_dist, hipStream_t s);
+size_t match_expand_bytes(int q_stride, int T, int t_stride, int nbatch);   // room d_expand must have; 0: pass nullptr
 int match_bruteforce_tsplit(int Q, int T, int nbatch);
 // static device scratch of the entry point that allocates nothing (one array per GPU, orbx_match.hip)
 constexpr size_t kMatchStaticScratchBytes = 4u << 20;

@@ -252,13 +252,43 @@ __device__ __forceinline__ void fp4_sweep(const v4i_t* __restrict__ a_frag, cons
     }
 }
 
+// 16 bytes per lane from memory straight into LDS: lane l's bytes land at lds_base + 16 * l.  Written as an assembly
+// statement on purpose: for the builtin of this instruction the compiler waits for every such load in flight before
+// each later LDS read (it cannot tell the buffer being filled from the one being read), which would put the memory
+// latency in front of every tile.  The caller waits for the loads itself (fp4_wait_loads) before the barrier that
+// publishes the buffer.  Loads complete in order, so the compiler's own counts for its own loads only get stricter.
+__device__ __forceinline__ void fp4_load_to_lds(const v4i_t* __restrict__ src_lane, uint32_t lds_base)
+{
+    // (m0 is not the compiler's to allocate: it loads it itself right before each instruction of its own that reads
+    // it; one wait state between a scalar write of m0 and an LDS load that reads it)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(src_lane), "s"(__builtin_amdgcn_readfirstlane(lds_base)) : "memory");
+}
+__device__ __forceinline__ void fp4_wait_loads() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Diagnostic builds (make EXTRA=-DORBX_MATCH_PROFILE): shader-clock cycles of one wavefront per part of a group of
+// tiles (expansion of the next fragments, wait at the barrier, sweeps), summed over all wavefronts.
+#ifdef ORBX_MATCH_PROFILE
+__device__ unsigned long long g_match_prof[8];
+#define MP_DECL unsigned long long mp_t = __builtin_readcyclecounter(), mp_acc[4] = {0, 0, 0, 0}
+#define MP_MARK(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); mp_acc[k] += n_ - mp_t; mp_t = n_; } while (0)
+#define MP_FLUSH() do { if (lane == 0) { for (int k_ = 0; k_ < 4; k_++) atomicAdd(&g_match_prof[k_], mp_acc[k_]); atomicAdd(&g_match_prof[4], 1ull); } } while (0)
+#else
+#define MP_DECL
+#define MP_MARK(k)
+#define MP_FLUSH()
+#endif
+
 // (four wavefronts per SIMD: at the 132 registers the compiler would take, three are resident and the sweep of eight
 // frames against one map is 3 % slower)
-template <int QT>
+// kPre: the train fragments and bit counts come expanded from memory (k_fp4_expand_trains wrote them once for all the
+// workgroups that sweep the same train set) instead of being expanded here by every workgroup: `t` is then the block
+// of fragments, [set][tile][k-step][lane] x 16 bytes, followed by the bit counts [set][tile][row], `tiles` tiles a set.
+template <int QT, bool kPre>
 __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_match_bruteforce_fp4(
     const uint32_t* __restrict__ q, int Q, int q_stride, const int32_t* __restrict__ nq, const uint32_t* __restrict__ t, int T,
     int t_stride, const int32_t* __restrict__ nt, int tsplit, uint32_t* __restrict__ partial, int32_t* __restrict__ best_idx,
-    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist)
+    int32_t* __restrict__ best_dist, int32_t* __restrict__ second_dist, int tiles, int nsets)
 {
     constexpr int NT = 4;                                       // tiles per barrier (1 / 2 / 4: 0.855 / 0.813 / 0.792 ms for 8 x 8000 x 100000)
     __shared__ v4i_t s_a[2][NT][4 * 64];                        // expanded train fragments: [buffer][tile of the group][k-step][lane]
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
     const int chunk = (((nT + tsplit - 1) / tsplit) + 31) & ~31;         // whole tiles per split
     const int j0 = min((int)blockIdx.y * chunk, nT), j1 = min(j0 + chunk, nT);
     // the first group's rows: positions 0.. of the first run
-    if (threadIdx.x < 32 * NT) s_c[0][threadIdx.x] = kRowBase + threadIdx.x + (j0 + (int)threadIdx.x < j1 ? 0u : kFp4Past);
+    if (!kPre && threadIdx.x < 32 * NT) s_c[0][threadIdx.x] = kRowBase + threadIdx.x + (j0 + (int)threadIdx.x < j1 ? 0u : kFp4Past);
     __syncthreads();
     const int q0 = (blockIdx.x * kFp4Waves + wave) * (32 * QT);
     if (blockIdx.x * kFp4Waves * (32 * QT) >= nQ) return;          // whole workgroup past the queries
@@ -291,7 +321,29 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
     // the first tile's train dwords are on their way while the queries are expanded
     const uint32_t* tp = t + (size_t)b * t_stride * 8 + 2 * wave + half;
     uint32_t mine = 0;
-    if (j0 < j1) mine = tp[8 * (size_t)min(j0 + r, j1 - 1)];
+    if (!kPre && j0 < j1) mine = tp[8 * (size_t)min(j0 + r, j1 - 1)];
+    // expanded form: this lane's 16 bytes of tile i are frag[i * 256]; the row counts of the set follow all fragments
+    const size_t set = t_stride ? (size_t)b : 0;
+    const v4i_t* frag = reinterpret_cast<const v4i_t*>(t) + set * tiles * 256 + wave * 64 + lane;
+    const uint32_t* rowpop = t + (size_t)nsets * tiles * 1024 + set * tiles * 32;
+    constexpr int kRunMask = (1 << kFp4RunBits) - 1;
+    auto start_value = [&](int jg, uint32_t pop) {            // of row jg + threadIdx.x, for threads below 32 * NT
+        return kRowBase + (pop << kFp4RunBits) + (uint32_t)(((jg - j0) & kRunMask) + (int)threadIdx.x) +
+               (jg + (int)threadIdx.x < j1 ? 0u : kFp4Past);
+    };
+    uint32_t pop_next = 0;
+    if (kPre) {
+        // the first group's fragments and start values; the second group's counts are on their way
+#pragma unroll
+        for (int k = 0; k < NT; k++)
+            if (j0 + 32 * k < j1) s_a[0][k][wave * 64 + lane] = frag[(size_t)(j0 / 32 + k) * 256];
+        if (threadIdx.x < 32 * NT) {
+            const int row = j0 + (int)threadIdx.x;
+            s_c[0][threadIdx.x] = start_value(j0, row < tiles * 32 ? rowpop[row] : 0u);
+            const int row2 = row + 32 * NT;
+            if (row2 < tiles * 32) pop_next = rowpop[row2];
+        }
+    }
 
     // queries: this lane's query of every tile, expanded once (B operand: the 32 bits 64 s + 32 half .. of k-step s)
     v4i_t bq[QT][4];
@@ -332,26 +384,58 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
     // of the row, and adds that dword's share of |b_r| to the row's start value, which a wavefront set up one group of
     // tiles ahead (three buffers: the group being swept, the group being built, and the one after it being set up).  Runs
     // of 4096 positions start at j0.
-    constexpr int kRunMask = (1 << kFp4RunBits) - 1;
     int buf = 0, cb = 0;
     uint32_t mn[NT];
     mn[0] = mine;
+    if (!kPre) {
 #pragma unroll
-    for (int k = 1; k < NT; k++) mn[k] = j0 + 32 * k < j1 ? tp[8 * (size_t)min(j0 + 32 * k + r, j1 - 1)] : 0u;
+        for (int k = 1; k < NT; k++) mn[k] = j0 + 32 * k < j1 ? tp[8 * (size_t)min(j0 + 32 * k + r, j1 - 1)] : 0u;
+    }
+    MP_DECL;
     for (int j = j0; j < j1; j += 32 * NT, buf ^= 1) {
+        MP_MARK(3);
+        int cn;
+        if (kPre) {
+            // Expanded form: while this group is swept, this wavefront's share of the next group's fragments goes from
+            // memory straight into the other buffer; the start values of the next group are written at the end (two
+            // buffers: every wavefront has passed this group's barrier, so nobody still reads the last group but one).
+            cn = cb ^ 1;
+            MP_MARK(0);
+            fp4_wait_loads();                                               // this group's fragments have landed
+            __syncthreads();
+            MP_MARK(1);
+            const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
+            const int jn = j + 32 * NT;
+#pragma unroll
+            for (int k = 0; k < NT; k++)
+                if (jn + 32 * k < j1)                                       // wave-uniform
+                    fp4_load_to_lds(frag + (size_t)(jn / 32 + k) * 256, (uint32_t)(uintptr_t)&s_a[buf ^ 1][k][wave * 64]);
+#pragma unroll
+            for (int k = 0; k < NT; k++)
+                if (active && j + 32 * k < j1) fp4_sweep<QT>(s_a[buf][k], c_rows + 32 * k, lane, half, bq, best, second);
+            if (threadIdx.x < 32 * NT) {
+                s_c[cn][threadIdx.x] = start_value(jn, pop_next);
+                const int row2 = jn + 32 * NT + (int)threadIdx.x;
+                pop_next = row2 < tiles * 32 ? rowpop[row2] : 0u;
+            }
+            if (active && ((jn - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
+            MP_MARK(2);
+            cb = cn;
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < NT; k++) {
             atomicAdd(&s_c[cb][32 * k + r], (uint32_t)__popc(mn[k]) << kFp4RunBits);
             s_a[buf][k][wave * 64 + lane] = expand32_fp4(s_lut, mn[k]);
         }
-        const int cn = cb == 2 ? 0 : cb + 1;
-        if (threadIdx.x < 32 * NT)
-            s_c[cn][threadIdx.x] = kRowBase + (uint32_t)(((j + 32 * NT - j0) & kRunMask) + (int)threadIdx.x) +
-                                   (j + 32 * NT + (int)threadIdx.x < j1 ? 0u : kFp4Past);
+        cn = cb == 2 ? 0 : cb + 1;
+        if (threadIdx.x < 32 * NT) s_c[cn][threadIdx.x] = start_value(j + 32 * NT, 0u);
 #pragma unroll
         for (int k = 0; k < NT; k++)
             if (j + 32 * (NT + k) < j1) mn[k] = tp[8 * (size_t)min(j + 32 * (NT + k) + r, j1 - 1)];
+        MP_MARK(0);
         __syncthreads();
+        MP_MARK(1);
         if (active) {
             const float* c_rows = reinterpret_cast<const float*>(s_c[cb]);
 #pragma unroll
@@ -360,8 +444,10 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
             }
             if (((j + 32 * NT - j0) & kRunMask) == 0) fold(j0 + ((j - j0) & ~kRunMask));
         }
+        MP_MARK(2);
         cb = cn;
     }
+    if (active) MP_FLUSH();
     if (!active) return;
     fold(j0 + ((j1 - 1 - j0) & ~kRunMask));   // (a whole number of runs: nothing left, and the fold of nothing is harmless)
 
@@ -391,6 +477,81 @@ __global__ __launch_bounds__(64 * kFp4Waves) __attribute__((amdgpu_waves_per_eu(
     }
 }
 
+#ifdef ORBX_MATCH_PROFILE
+}  // namespace orbx
+extern "C" int orbx_debug_match_profile(unsigned long long* out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(orbx::g_match_prof), 8 * sizeof(unsigned long long)) != hipSuccess) return -3;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(orbx::g_match_prof), z, sizeof(z)) != hipSuccess) return -3;
+    }
+    return 0;
+}
+namespace orbx {
+#endif
+
+// Train descriptors -> the matrix form of k_match_bruteforce_fp4<.., true>: one workgroup per tile of 32 descriptors,
+// wavefront w expands k-step w (dword 2 w + half of row lane & 31) exactly as the sweep itself would, rows past the
+// set's end repeat its last descriptor; the rows' bit counts go behind all fragments.
+__global__ __launch_bounds__(64 * kFp4Waves) void k_fp4_expand_trains(const uint32_t* __restrict__ t, int T, int t_stride,
+                                                                      const int32_t* __restrict__ nt, uint32_t* __restrict__ out,
+                                                                      int tiles, int nsets)
+{
+    __shared__ uint32_t s_lut[256];
+    __shared__ uint32_t s_pop[32];
+    const int set = blockIdx.y, tile = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v |= ((threadIdx.x >> i) & 1u) << (4 * i + 1);
+        s_lut[threadIdx.x] = v;
+    }
+    if (threadIdx.x < 32) s_pop[threadIdx.x] = 0u;
+    __syncthreads();
+    const int nT = nt ? min(nt[set], T) : T;
+    uint32_t dw = 0u;
+    if (nT > 0) dw = t[((size_t)set * t_stride + (size_t)min(32 * tile + r, nT - 1)) * 8 + 2 * wave + half];
+    reinterpret_cast<v4i_t*>(out)[((size_t)set * tiles + tile) * 256 + wave * 64 + lane] = expand32_fp4(s_lut, dw);
+    atomicAdd(&s_pop[r], (uint32_t)__popc(dw));
+    __syncthreads();
+    if (threadIdx.x < 32) out[(size_t)nsets * tiles * 1024 + ((size_t)set * tiles + tile) * 32 + threadIdx.x] = s_pop[threadIdx.x];
+}
+
+// The environment switches of the brute-force search are read once per process; only a process started with
+// ORBX_SWITCHES_PER_CALL set (the tests, which compare the forms) reads them again at every call.
+// ORBX_MATCH_FORM=scalar: the xor / popcount sweep for every size.  ORBX_MATCH_EXPAND=0 / 1: never / whenever possible
+// expand the train set once in memory instead of in every workgroup.
+static bool match_want_scalar()
+{
+    auto read = [] { const char* e = getenv("ORBX_MATCH_FORM"); return e && e[0] == 's'; };
+    static const bool per_call = getenv("ORBX_SWITCHES_PER_CALL") != nullptr;
+    static const bool at_start = read();
+    return per_call ? read() : at_start;
+}
+static int match_expand_mode()
+{
+    auto read = [] { const char* e = getenv("ORBX_MATCH_EXPAND"); return e ? atoi(e) : -1; };
+    static const bool per_call = getenv("ORBX_SWITCHES_PER_CALL") != nullptr;
+    static const int at_start = read();
+    return per_call ? read() : at_start;
+}
+
+// Bytes of the expanded train sets (fragments + bit counts) when the search is to use them, 0 when every workgroup
+// expands for itself: the expanded form pays when many workgroups sweep the same set (each tile of 256 queries is one).
+size_t match_expand_bytes(int q_stride, int T, int t_stride, int nbatch)
+{
+    if (match_want_scalar() || T < 64 || q_stride < 32) return 0;
+    const int mode = match_expand_mode();
+    if (mode == 0) return 0;
+    const long sweeps_per_set = (long)((q_stride + 255) / 256) * (t_stride ? 1 : nbatch);
+    // (measured: 32 sweeps of one set of 100 000 lose 4 us to the extra launch, 256 sweeps gain 24 us)
+    if (mode < 0 && (sweeps_per_set < 64 || T < 4096)) return 0;
+    const size_t tiles = (size_t)(T + 31) / 32, nsets = t_stride ? (size_t)nbatch : 1;
+    return nsets * tiles * (4096 + 128);
+}
+
 int match_bruteforce_tsplit(int Q, int T, int nbatch)
 {
     // chunks of >= 256 train descriptors
@@ -412,21 +573,25 @@ int match_bruteforce_tsplit(int Q, int T, int nbatch)
 
 void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int32_t* d_nq,
                              const uint32_t* d_t, int T, int t_stride, const int32_t* d_nt, int nbatch,
-                             int tsplit, uint32_t* d_partial, int32_t* d_best_idx, int32_t* d_best_dist,
+                             int tsplit, uint32_t* d_partial, uint32_t* d_expand, int32_t* d_best_idx, int32_t* d_best_dist,
                              int32_t* d_second_dist, hipStream_t s)
 {
-    // the matrix-core sweep needs whole tiles to pay: tiny problems keep the scalar form.  ORBX_MATCH_FORM=scalar takes
-    // it for every size.  The environment is read once per process; only a process started with
-    // ORBX_SWITCHES_PER_CALL set (the tests, which compare the two forms) reads it again at every call.
-    auto want_scalar = [] { const char* e = getenv("ORBX_MATCH_FORM"); return e && e[0] == 's'; };
-    static const bool per_call = getenv("ORBX_SWITCHES_PER_CALL") != nullptr;
-    static const bool scalar_at_start = want_scalar();
-    const bool scalar = per_call ? want_scalar() : scalar_at_start;
-    if (!scalar && T >= 64 && q_stride >= 32) {
+    // the matrix-core sweep needs whole tiles to pay: tiny problems keep the scalar form; d_expand: room for
+    // match_expand_bytes() when that is not 0
+    if (!match_want_scalar() && T >= 64 && q_stride >= 32) {
         const int per_wg = kFp4Waves * 32 * kMfmaQT;
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
-        hipLaunchKernelGGL(k_match_bruteforce_fp4<kMfmaQT>, grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq, d_t, T,
-                           t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist);
+        const int tiles = (T + 31) / 32, nsets = t_stride ? nbatch : 1;
+        if (d_expand) {
+            hipLaunchKernelGGL(k_fp4_expand_trains, dim3(tiles, nsets), dim3(64 * kFp4Waves), 0, s, d_t, T, t_stride, d_nt,
+                               d_expand, tiles, nsets);
+            hipLaunchKernelGGL((k_match_bruteforce_fp4<kMfmaQT, true>), grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq,
+                               d_expand, T, t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist, tiles,
+                               nsets);
+        } else {
+            hipLaunchKernelGGL((k_match_bruteforce_fp4<kMfmaQT, false>), grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq,
+                               d_t, T, t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist, tiles, nsets);
+        }
     } else {
         dim3 grid((q_stride + 255) / 256, tsplit, nbatch);
         hipLaunchKernelGGL(k_match_bruteforce, grid, dim3(256), 0, s, d_q, Q, q_stride, d_nq, d_t, T, t_stride, d_nt,

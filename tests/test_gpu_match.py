@@ -37,13 +37,26 @@ def test_descriptor_distance(matcher, oracle):
         assert ORBmatcher.DescriptorDistance(a, b) == ref == oracle.hamming(a, b)
 
 
-FORMS = ["auto", "scalar"]     # the library's own choice (the matrix-core sweep from 64 train descriptors on) and the scalar sweep
+# the library's own choice (the matrix-core sweep from 64 train descriptors on, the train set expanded in memory when many
+# query tiles share it), the scalar sweep, and the matrix-core sweep on train sets expanded in memory at every size
+FORMS = ["auto", "scalar", "expanded"]
+
+
+def _set_form(monkeypatch, f):
+    """The library reads these switches at every call (tests/conftest.py sets ORBX_SWITCHES_PER_CALL)."""
+    monkeypatch.delenv("ORBX_MATCH_FORM", raising=False)
+    monkeypatch.delenv("ORBX_MATCH_EXPAND", raising=False)
+    if f == "scalar":
+        monkeypatch.setenv("ORBX_MATCH_FORM", "scalar")
+    elif f == "expanded":
+        monkeypatch.setenv("ORBX_MATCH_EXPAND", "1")
+    elif f == "in-kernel":
+        monkeypatch.setenv("ORBX_MATCH_EXPAND", "0")
 
 
 @pytest.fixture(params=FORMS)
 def form(request, monkeypatch):
-    if request.param != "auto":
-        monkeypatch.setenv("ORBX_MATCH_FORM", request.param)      # read by the library at every call
+    _set_form(monkeypatch, request.param)
     return request.param
 
 
@@ -111,12 +124,13 @@ def test_bruteforce_long_runs(matcher, oracle, monkeypatch):
     t[T - 1] = q[11]
     t[100000] = q[13] ^ np.uint8(1)            # one bit per byte off: distance 32, far below a random pair's
     res = {}
-    for f in ("scalar", "auto"):
-        monkeypatch.setenv("ORBX_MATCH_FORM", f)
+    for f in ("scalar", "in-kernel", "expanded"):
+        _set_form(monkeypatch, f)
         res[f] = matcher.match_bruteforce(q, t)
-    for a, b in zip(res["scalar"], res["auto"]):
-        assert np.array_equal(a, b)
-    bi, bd, sd = res["auto"]
+    for f in ("in-kernel", "expanded"):
+        for a, b in zip(res["scalar"], res[f]):
+            assert np.array_equal(a, b), f
+    bi, bd, sd = res["expanded"]
     assert bi[7] == 4095 and bd[7] == 0 and sd[7] == 0
     assert bi[9] == 4096 + 4095 and sd[9] == 0
     assert bi[11] == T - 1 and bd[11] == 0
@@ -138,8 +152,8 @@ def test_bruteforce_largest_train_set(matcher, oracle, monkeypatch):
     t[T - 2] = q[4] ^ np.uint8(128)
     oi, od, os_ = oracle.match_bruteforce(q, t)
     assert oi[3] == T - 1 and od[3] == 0
-    for f in ("auto", "scalar"):
-        monkeypatch.setenv("ORBX_MATCH_FORM", f)
+    for f in ("in-kernel", "scalar", "expanded"):
+        _set_form(monkeypatch, f)
         bi, bd, sd = matcher.match_bruteforce(q, t)
         assert np.array_equal(bi, oi) and np.array_equal(bd, od) and np.array_equal(sd, os_), f
     with pytest.raises(OrbxError):

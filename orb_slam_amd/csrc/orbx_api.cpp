@@ -282,7 +282,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
         const bool aligned = (((uintptr_t)d_imgs | (uintptr_t)frame_stride | (uintptr_t)stride | (uintptr_t)w) & 3u) == 0;
         // every consumer of level 0 has its image form only on the ordinary path: sliding-window resize, some FAST cells
         // on level 0, an image tall and wide enough for a single reflection, offsets that fit 32 bits and 16 bits
-        if (src_on_device && !no_raw && !pyramid_only && aligned && g0.resize_slide_ok && g0.nlevels > 1 && !c->h_cells0.empty() &&
+        if (src_on_device && !no_raw && !pyramid_only && g0.resize_slide_ok && g0.nlevels > 1 && !c->h_cells0.empty() &&
             w >= 64 && h >= 64 && stride <= 65532 && (size_t)stride * (size_t)h < ((size_t)1 << 31)) {
             if (c->raw_stride != stride) {
                 // the tables addressed into an image with this row stride (plane offsets -> image offsets)
@@ -315,6 +315,7 @@ int run_batch(orbx_ctx* c, const uint8_t* d_imgs, int nframes, int w, int h, int
             raw.stride = stride;
             raw.ncells0 = (int)c->h_cells0.size();
             raw.on = 1;
+            raw.any_alignment = aligned ? 0 : 1;
         }
     }
     const FrameGeom& g = c->g;

@@ -164,23 +164,42 @@ __device__ __forceinline__ uint32_t hpair(const Unaligned8 s, uint32_t sel, uint
 // read through a buffer descriptor that covers exactly the frame (the 12-byte windows of the last columns run a few
 // bytes past their row, which at the end of the last row would be past the caller's buffer: such bytes read as zero
 // and carry no weight).
-template <bool RAW>
+// ANY (RAW only; src_w = width of the image): an image whose rows start at any byte.  The lane then loads its 8 bytes
+// where they lie; a window that would run past its row starts 8 bytes before the row's end instead, with the byte
+// selectors moved along: a dword that straddles the end of the buffer descriptor reads as zero as a whole, valid bytes
+// included, and nothing may be read past the caller's last row.
+template <bool RAW, bool ANY = false>
 __device__ __forceinline__ void resize_band(uint8_t* frame, const uint8_t* src, uint32_t src_bytes, const LevelGeom& L,
                                             const XTab4* __restrict__ xtab, const YTab2* __restrict__ yt,
-                                            int dwc, int r0, int r1, int mirror)
+                                            int dwc, int r0, int r1, int mirror, int src_w = 0)
 {
-    const XTab4 x = xtab[L.xtab4_off + dwc];
+    XTab4 x = xtab[L.xtab4_off + dwc];
+    if (ANY) {
+        const uint32_t start = min(x.base, (uint32_t)(src_w - 8));
+        const uint32_t sh = x.base - start;                          // 0 .. 7
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t ia = min((x.sel[j] & 7u) + sh, 7u), ib = min(((x.sel[j] >> 16) & 7u) + sh, 7u);   // (a byte past the row has no weight)
+            x.sel[j] = ia | (0x0cu << 8) | (ib << 16) | (0x0cu << 24);
+        }
+        x.base = start;
+    }
     // The 8 source bytes of this lane start at an arbitrary byte; a misaligned vector load is split
     // into many cache accesses, so fetch the 3 aligned dwords around them and shift (row offsets,
     // plane offsets and pitches are multiples of 4: the misalignment is the lane's constant).
-    const uint32_t shx = x.base & 3u;
+    const uint32_t shx = ANY ? 0u : x.base & 3u;
     // addresses = wave-uniform row pointer + the lane's 32-bit offset: the form a global load / store
     // takes as scalar base + vector offset, with no 64-bit vector arithmetic per access
     uint8_t* dst = frame + L.plane_off;
-    const uint32_t xoff = x.base & ~3u, doff = 4u * (uint32_t)dwc;
+    const uint32_t xoff = ANY ? x.base : x.base & ~3u, doff = 4u * (uint32_t)dwc;
     const int rlast = L.rows - 1;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, RAW ? (int)src_bytes : 0, 0x00020000);
     auto load12 = [&](uint32_t row_off) -> Aligned12 {
+        if (RAW && ANY) {
+            typedef unsigned int v2u_t __attribute__((ext_vector_type(2)));
+            const v2u_t v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)xoff, (int)row_off, 0);
+            return Aligned12{v.x, v.y, 0u};
+        }
         if (RAW) {
             typedef unsigned int v3u_t __attribute__((ext_vector_type(3)));
             const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)xoff, (int)row_off, 0);
@@ -269,7 +288,9 @@ __global__ __launch_bounds__(256) void k_resize_slide(uint8_t* __restrict__ pyr,
     const int r0 = __builtin_amdgcn_readfirstlane(row_lo + rb * rows_per_band), r1 = min(r0 + rows_per_band, row_hi);
     if (dwc * 4 >= L.pitch || r0 >= row_hi) return;
     uint8_t* frame = pyr + (size_t)blockIdx.y * g.pyr_frame_bytes;
-    if (raw.on && level == 1)
+    if (raw.on && level == 1 && raw.any_alignment)
+        resize_band<true, true>(frame, raw.base + (size_t)blockIdx.y * raw.frame_stride, raw.frame_bytes, L, xtab, raw.ytab2_l1, dwc, r0, r1, mirror, g.lv[0].w);
+    else if (raw.on && level == 1)
         resize_band<true>(frame, raw.base + (size_t)blockIdx.y * raw.frame_stride, raw.frame_bytes, L, xtab, raw.ytab2_l1, dwc, r0, r1, mirror);
     else
         resize_band<false>(frame, frame + g.lv[level - 1].plane_off, 0u, L, xtab, ytab + L.ytab2_off, dwc, r0, r1, mirror);
@@ -413,7 +434,7 @@ __device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8
         typedef unsigned int v3u_t __attribute__((ext_vector_type(3)));
         const uint32_t spitch = (uint32_t)raw.stride;
         const int last_n = ((nrows + 5) / 6) * 6 + 5;                    // last source row counter a band loads
-        const bool edge = dw == 0 || dw == ndw - 1 || y0 < 3 || y0 - 3 + last_n > L.h - 1;
+        const bool edge = dw == 0 || 4 * dw + 7 >= L.w || y0 < 3 || y0 - 3 + last_n > L.h - 1;
         if (__ballot(edge) == 0ull) {                                     // wave-uniform: no lane needs a pixel outside the image
             const uint32_t soff = __umul24((uint32_t)(y0 - 3), spitch) + (uint32_t)(4 * dw - 4);
             blur_band([&](int nb, int p, uint32_t& a, uint32_t& b, uint32_t& c) {
@@ -422,22 +443,41 @@ __device__ __forceinline__ void blur_item(const uint8_t* __restrict__ pyr, uint8
                 a = v.x; b = v.y; c = v.z;
             }, dst, doff, pitch, nrows);
         } else {
-            // REFLECT_101 formed here: rows by index (row -r is row r, row h - 1 + r is row h - 1 - r), the three pixels
-            // left of column 0 and right of column w - 1 by byte permutes of the dwords next to them
-            const bool left = dw == 0, right = dw == ndw - 1;
+            // REFLECT_101 formed here: rows by index (row -r is row r, row h - 1 + r is row h - 1 - r), columns by byte
+            // permutes.  A lane loads 12 bytes that lie inside its row (the first 12 for the leftmost lane, the last 12 for
+            // the lanes whose taps reach past column w - 1, its own 12 otherwise) and cuts its three dwords (pixels
+            // 4 dw - 4 .. 4 dw + 7) out of them: each is four bytes of one pair of adjacent loaded dwords, through a
+            // selector computed here once per band.  Any width: the last dword column holds 1 to 4 pixels.
+            const int X = 4 * dw, w = L.w;
+            const bool left = dw == 0, rightish = X + 7 >= w;         // (a 12-byte load must not cross the end of the last row)
             const int h2 = 2 * L.h - 2;
-            // an edge lane loads the 12 bytes that lie inside its row (columns 0 .. 11, or the last 12), so that no load
-            // leaves the frame, and moves them into place
-            const uint32_t coff = left ? 0u : (uint32_t)(right ? 4 * dw - 8 : 4 * dw - 4);
+            const int coff = left ? 0 : (rightish ? w - 12 : X - 4);
+            uint32_t sel[3];
+            bool upper[3];                                                  // the dword's bytes come from (v.y, v.z), not (v.x, v.y)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                int idx[4], lo = 12;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    int col = X - 4 + 4 * q + j;
+                    col = col < 0 ? -col : (col >= w ? 2 * (w - 1) - col : col);
+                    idx[j] = min(max(col - coff, 0), 11);                   // (the unused bytes 0 and 11 may fall outside)
+                    lo = min(lo, idx[j]);
+                }
+                upper[q] = lo >= 4;
+                const int m4 = upper[q] ? 4 : 0;
+                sel[q] = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) sel[q] |= (uint32_t)min(idx[j] - m4, 7) << (8 * j);
+            }
             blur_band([&](int nb, int p, uint32_t& a, uint32_t& b, uint32_t& c) {
                 int r = y0 - 3 + nb + p;
                 r = max(r, -r);
                 r = min(r, h2 - r);
-                const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(__umul24((uint32_t)r, spitch) + coff), 0, 0);
-                const uint32_t cw = left ? v.x : (right ? v.z : v.y);
-                a = left ? __builtin_amdgcn_perm(v.y, v.x, 0x01020304u) : (right ? v.y : v.x);   // pixels -4 .. -1 = pixels 4, 3, 2, 1
-                b = cw;
-                c = right ? __builtin_amdgcn_perm(0u, cw, 0x00000102u) : (left ? v.y : v.z);     // pixels w .. w+2 = pixels w-2, w-3, w-4
+                const v3u_t v = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(__umul24((uint32_t)r, spitch) + (uint32_t)coff), 0, 0);
+                a = __builtin_amdgcn_perm(upper[0] ? v.z : v.y, upper[0] ? v.y : v.x, sel[0]);
+                b = __builtin_amdgcn_perm(upper[1] ? v.z : v.y, upper[1] ? v.y : v.x, sel[1]);
+                c = __builtin_amdgcn_perm(upper[2] ? v.z : v.y, upper[2] ? v.y : v.x, sel[2]);
             }, dst, doff, pitch, nrows);
         }
         return;

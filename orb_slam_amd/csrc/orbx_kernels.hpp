@@ -38,8 +38,7 @@ struct CountLevels {
 
 struct ScaleTab { float v[kMaxLevels]; };
 
-// Level 0 read from the caller's image instead of a copy of it in the pyramid block (resident batches whose rows are
-// dword-addressable): the FAST cells, the blur, the resize into level 1 and the orientation patches of level 0 take
+// Level 0 read from the caller's image instead of a copy of it in the pyramid block (resident batches): the FAST cells, the blur, the resize into level 1 and the orientation patches of level 0 take
 // their pixels from `base`; only the blur ever needs pixels outside the image (3 of them, REFLECT_101), and forms them
 // itself.  on == 0: every level is read from the pyramid block.
 struct RawL0 {
@@ -51,6 +50,7 @@ struct RawL0 {
     int stride = 0;                        // bytes per image row
     int ncells0 = 0;                       // FAST cells of level 0 (the first cells of a frame)
     int on = 0;
+    int any_alignment = 0;                 // base, strides or width are not multiples of 4: byte-addressed loads
 };
 
 int upload_constant_tables(const int* gauss7, const int* umax16, hipStream_t s);

@@ -102,12 +102,14 @@ def test_large_batch_shapes(gpu, oracle, euroc_left):
 
 @pytest.mark.parametrize("w,h,nfeat,pad,gap", [(752, 480, 1000, 0, 0), (752, 480, 1000, 12, 4096), (640, 481, 800, 4, 8),
                                                    (1024, 256, 1200, 0, 0), (316, 243, 500, 0, 0), (64, 64, 100, 8, 0),
-                                                   (2048, 1100, 3000, 0, 0)])
+                                                   (2048, 1100, 3000, 0, 0), (1241, 376, 2000, 0, 0), (318, 243, 500, 0, 0),
+                                                   (755, 480, 1000, 0, 3), (642, 300, 800, 5, 1), (65, 67, 100, 0, 0)])
 def test_level0_read_from_the_image(w, h, nfeat, pad, gap, monkeypatch):
-    """Resident batches whose rows are dword-addressable read level 0 where it lies instead of copying it into the
-    pyramid block first (FAST cells, blur with its own REFLECT_101, resize into level 1, orientation patches); the
-    level-0 plane is made on demand.  Every stage against the oracle, with a row stride wider than the image and a gap
-    between frames, and the same call with the copy switched back on."""
+    """Resident batches read level 0 where it lies instead of copying it into the pyramid block first (FAST cells,
+    blur with its own REFLECT_101, resize into level 1, orientation patches); the level-0 plane is made on demand.
+    Every stage against the oracle, with a row stride wider than the image and a gap between frames, widths and
+    strides that are no multiples of 4 (rows that start at any byte, a last dword column of 1 to 3 pixels), an odd
+    base address, and the same call with the copy switched back on."""
     import torch
     from orb_slam_amd import ORBextractor
     o = Oracle(nfeat, 1.2, 8, 20, 7)
@@ -127,7 +129,7 @@ def test_level0_read_from_the_image(w, h, nfeat, pad, gap, monkeypatch):
             monkeypatch.setenv("ORBX_NO_RAW0", "1")
         else:
             monkeypatch.delenv("ORBX_NO_RAW0", raising=False)
-        shift = 1 if "unaligned" in mode else 0                  # an odd base address: the copy is taken by itself
+        shift = 1 if "unaligned" in mode else 0                  # an odd base address
         d_buf = torch.from_numpy(np.concatenate([np.zeros(shift, np.uint8), buf])).to(dev)
         d_k = torch.zeros((B, cap, 7), dtype=torch.float32, device=dev)
         d_d = torch.zeros((B, cap, 32), dtype=torch.uint8, device=dev)

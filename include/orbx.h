@@ -155,7 +155,10 @@ int orbx_match_bruteforce(orbx_ctx *ctx, const uint32_t *q, int Q, const uint32_
 /* Device-resident, asynchronous, batched: batch b uses queries
  * d_q + b*q_stride*8 (count d_nq[b] <= q_stride, or Q if d_nq == NULL) against
  * train descriptors d_t + b*t_stride*8 (count d_nt[b] or T; t_stride = 0
- * shares one train set).  Outputs are [nbatch][q_stride]. */
+ * shares one train set).  Outputs are [nbatch][q_stride].  May grow two buffers of the
+ * context (partial results of the train splits; 132 bytes per train descriptor when 64 or
+ * more tiles of 256 queries sweep one train set); the call that grows one waits for the
+ * context's earlier work first. */
 int orbx_match_bruteforce_device(orbx_ctx *ctx, const uint32_t *d_q, int Q, int q_stride, const int32_t *d_nq,
                                  const uint32_t *d_t, int T, int t_stride, const int32_t *d_nt, int nbatch,
                                  int32_t *d_best_idx, int32_t *d_best_dist, int32_t *d_second_dist);

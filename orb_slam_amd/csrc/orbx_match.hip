@@ -492,11 +492,10 @@ namespace orbx {
 #endif
 
 // Train descriptors -> the matrix form of k_match_bruteforce_fp4<.., true>: one workgroup per tile of 32 descriptors,
-// wavefront w expands k-step w (dword 2 w + half of row lane & 31) exactly as the sweep itself would, rows past the
-// set's end repeat its last descriptor; the rows' bit counts go behind all fragments.
+// wavefront w expands k-step w (dword 2 w + half of row lane & 31) exactly as the sweep itself would, the rows past
+// row T - 1 of the last tile repeat that row; the rows' bit counts go behind all fragments.
 __global__ __launch_bounds__(64 * kFp4Waves) void k_fp4_expand_trains(const uint32_t* __restrict__ t, int T, int t_stride,
-                                                                      const int32_t* __restrict__ nt, uint32_t* __restrict__ out,
-                                                                      int tiles, int nsets)
+                                                                      uint32_t* __restrict__ out, int tiles, int nsets)
 {
     __shared__ uint32_t s_lut[256];
     __shared__ uint32_t s_pop[32];
@@ -510,9 +509,9 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_fp4_expand_trains(const uint
     }
     if (threadIdx.x < 32) s_pop[threadIdx.x] = 0u;
     __syncthreads();
-    const int nT = nt ? min(nt[set], T) : T;
-    uint32_t dw = 0u;
-    if (nT > 0) dw = t[((size_t)set * t_stride + (size_t)min(32 * tile + r, nT - 1)) * 8 + 2 * wave + half];
+    // all T rows of the set, whatever the batches' own counts (a set shared by the whole batch has one count per batch;
+    // the sweep ignores the rows past its batch's count)
+    const uint32_t dw = t[((size_t)set * t_stride + (size_t)min(32 * tile + r, T - 1)) * 8 + 2 * wave + half];
     reinterpret_cast<v4i_t*>(out)[((size_t)set * tiles + tile) * 256 + wave * 64 + lane] = expand32_fp4(s_lut, dw);
     atomicAdd(&s_pop[r], (uint32_t)__popc(dw));
     __syncthreads();
@@ -583,7 +582,7 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
         const int tiles = (T + 31) / 32, nsets = t_stride ? nbatch : 1;
         if (d_expand) {
-            hipLaunchKernelGGL(k_fp4_expand_trains, dim3(tiles, nsets), dim3(64 * kFp4Waves), 0, s, d_t, T, t_stride, d_nt,
+            hipLaunchKernelGGL(k_fp4_expand_trains, dim3(tiles, nsets), dim3(64 * kFp4Waves), 0, s, d_t, T, t_stride,
                                d_expand, tiles, nsets);
             hipLaunchKernelGGL((k_match_bruteforce_fp4<kMfmaQT, true>), grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq,
                                d_expand, T, t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist, tiles,

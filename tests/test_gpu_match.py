@@ -213,6 +213,32 @@ def test_bruteforce_device_batched(ex, matcher, oracle, form):
         assert np.array_equal(outs[2][b, :nq[b]].cpu().numpy(), os_)
 
 
+def test_bruteforce_device_batch_shares_one_train_set(ex, matcher, oracle, form):
+    """Every batch searches the same train set (train stride 0), each up to its own count of train descriptors: the
+    counts differ per batch, the first batch's is the smallest."""
+    torch = pytest.importorskip("torch")
+    nb, qs, T = 4, 300, 5000
+    rng = np.random.default_rng(23)
+    q = rng.integers(0, 256, (nb, qs, 32), dtype=np.uint8)
+    t = rng.integers(0, 256, (T, 32), dtype=np.uint8)
+    nq = np.array([300, 17, 256, 299], np.int32)
+    nt = np.array([70, 5000, 4097, 33], np.int32)
+    t[4500] = q[1, 3]                       # beyond the first batch's count: batch 1 must find it, batch 0 must not see it
+    dev = torch.device("cuda:0")
+    dq, dt, dnq, dnt = [torch.from_numpy(a).to(dev) for a in (q, t, nq, nt)]
+    outs = [torch.full((nb, qs), -7, dtype=torch.int32, device=dev) for _ in range(3)]
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    matcher.match_bruteforce_device(dq, qs, qs, dnq, dt, T, 0, dnt, nb, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    got = [o.cpu().numpy() for o in outs]
+    assert got[0][1, 3] == 4500 and got[1][1, 3] == 0
+    for b in range(nb):
+        ref = oracle.match_bruteforce(q[b, :nq[b]], t[:nt[b]])
+        for g, r in zip(got, ref):
+            assert np.array_equal(g[b, :nq[b]], r)
+
+
 def test_bruteforce_device_batched_empty_sets_and_padded_strides(ex, matcher, oracle, form):
     """Batches with no queries or no train descriptors at all, counts of 1, and strides larger than the counts:
     an empty train set answers -1 / 256 / 256, an empty query set writes nothing."""

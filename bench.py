@@ -644,7 +644,7 @@ def main():
             call_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / reps
             tflops = pairs * 512 / (call_ms * 1e-3) / 1e12          # 256 multiply-adds per pair of 256-bit descriptors
             formal = 32 * (nq + nt) + 12 * nq
-            roof = {"bound": "mfma", "kernel": "k_match_bruteforce_fp4 (+ k_match_merge)", "achieved": round(tflops, 1),
+            roof = {"bound": "mfma", "kernel": "k_match_bruteforce_fp4 (+ k_fp4_expand_trains where many query tiles share a train set, k_match_merge)", "achieved": round(tflops, 1),
                     "peak": FP4_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tflops / FP4_PEAK_TFLOPS, 4), "traffic": None,
                     "kernel_ms": round(call_ms, 4),
                     "flops_note": "pair distances x 512 (256-bit inner product as block-scaled FP4 matrix instructions) against the "

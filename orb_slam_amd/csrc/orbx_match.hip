@@ -494,12 +494,13 @@ namespace orbx {
 // Train descriptors -> the matrix form of k_match_bruteforce_fp4<.., true>: one workgroup per tile of 32 descriptors,
 // wavefront w expands k-step w (dword 2 w + half of row lane & 31) exactly as the sweep itself would, the rows past
 // row T - 1 of the last tile repeat that row; the rows' bit counts go behind all fragments.
+constexpr int kExpandTiles = 4;         // tiles per workgroup of k_fp4_expand_trains (one table set-up and one barrier for all)
 __global__ __launch_bounds__(64 * kFp4Waves) void k_fp4_expand_trains(const uint32_t* __restrict__ t, int T, int t_stride,
                                                                       uint32_t* __restrict__ out, int tiles, int nsets)
 {
     __shared__ uint32_t s_lut[256];
-    __shared__ uint32_t s_pop[32];
-    const int set = blockIdx.y, tile = blockIdx.x;
+    __shared__ uint32_t s_pop[kExpandTiles][32];
+    const int set = blockIdx.y, tile0 = blockIdx.x * kExpandTiles;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
     {
         uint32_t v = 0;
@@ -507,15 +508,24 @@ __global__ __launch_bounds__(64 * kFp4Waves) void k_fp4_expand_trains(const uint
         for (int i = 0; i < 8; i++) v |= ((threadIdx.x >> i) & 1u) << (4 * i + 1);
         s_lut[threadIdx.x] = v;
     }
-    if (threadIdx.x < 32) s_pop[threadIdx.x] = 0u;
-    __syncthreads();
+    if (threadIdx.x < 32 * kExpandTiles) (&s_pop[0][0])[threadIdx.x] = 0u;
     // all T rows of the set, whatever the batches' own counts (a set shared by the whole batch has one count per batch;
     // the sweep ignores the rows past its batch's count)
-    const uint32_t dw = t[((size_t)set * t_stride + (size_t)min(32 * tile + r, T - 1)) * 8 + 2 * wave + half];
-    reinterpret_cast<v4i_t*>(out)[((size_t)set * tiles + tile) * 256 + wave * 64 + lane] = expand32_fp4(s_lut, dw);
-    atomicAdd(&s_pop[r], (uint32_t)__popc(dw));
+    uint32_t dw[kExpandTiles];
+#pragma unroll
+    for (int k = 0; k < kExpandTiles; k++)
+        dw[k] = tile0 + k < tiles ? t[((size_t)set * t_stride + (size_t)min(32 * (tile0 + k) + r, T - 1)) * 8 + 2 * wave + half] : 0u;
     __syncthreads();
-    if (threadIdx.x < 32) out[(size_t)nsets * tiles * 1024 + ((size_t)set * tiles + tile) * 32 + threadIdx.x] = s_pop[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < kExpandTiles; k++) {
+        if (tile0 + k >= tiles) break;
+        reinterpret_cast<v4i_t*>(out)[((size_t)set * tiles + tile0 + k) * 256 + wave * 64 + lane] = expand32_fp4(s_lut, dw[k]);
+        atomicAdd(&s_pop[k][r], (uint32_t)__popc(dw[k]));
+    }
+    __syncthreads();
+    const int k = threadIdx.x >> 5;
+    if (k < kExpandTiles && tile0 + k < tiles)
+        out[(size_t)nsets * tiles * 1024 + ((size_t)set * tiles + tile0 + k) * 32 + (threadIdx.x & 31)] = s_pop[k][threadIdx.x & 31];
 }
 
 // The environment switches of the brute-force search are read once per process; only a process started with
@@ -582,7 +592,7 @@ void launch_match_bruteforce(const uint32_t* d_q, int Q, int q_stride, const int
         dim3 grid((q_stride + per_wg - 1) / per_wg, tsplit, nbatch);
         const int tiles = (T + 31) / 32, nsets = t_stride ? nbatch : 1;
         if (d_expand) {
-            hipLaunchKernelGGL(k_fp4_expand_trains, dim3(tiles, nsets), dim3(64 * kFp4Waves), 0, s, d_t, T, t_stride,
+            hipLaunchKernelGGL(k_fp4_expand_trains, dim3((tiles + kExpandTiles - 1) / kExpandTiles, nsets), dim3(64 * kFp4Waves), 0, s, d_t, T, t_stride,
                                d_expand, tiles, nsets);
             hipLaunchKernelGGL((k_match_bruteforce_fp4<kMfmaQT, true>), grid, dim3(64 * kFp4Waves), 0, s, d_q, Q, q_stride, d_nq,
                                d_expand, T, t_stride, d_nt, tsplit, d_partial, d_best_idx, d_best_dist, d_second_dist, tiles,

@@ -1106,6 +1106,13 @@ int orbx_match_bruteforce_device(orbx_ctx* c, const uint32_t* d_q, int Q, int q_
     if (T >= (1 << 22)) return fail(c, ORBX_ERR_UNSUPPORTED, "train set of 2^22 descriptors or more");
     if (q_stride == 0) return ORBX_OK;
     HIPCHECK(c, hipSetDevice(c->device));
+    // Dense batches against one shared train set are one long list of queries: taken as a single batch, so that only
+    // the list's last tile of 256 queries can be short instead of every batch's (the outputs lie the same way).
+    if (t_stride == 0 && !d_nq && !d_nt && q_stride == Q && nbatch > 1 && (long long)Q * nbatch < (1ll << 30)) {
+        Q *= nbatch;
+        q_stride = Q;
+        nbatch = 1;
+    }
     int tsplit = match_bruteforce_tsplit(q_stride, T, nbatch);
     if (tsplit > 1) {
         size_t need = (size_t)nbatch * tsplit * q_stride * 8;

@@ -237,6 +237,16 @@ def test_bruteforce_device_batch_shares_one_train_set(ex, matcher, oracle, form)
         ref = oracle.match_bruteforce(q[b, :nq[b]], t[:nt[b]])
         for g, r in zip(got, ref):
             assert np.array_equal(g[b, :nq[b]], r)
+    # the same set, every batch dense: the library takes the batches as one list of queries
+    ex.set_stream(torch.cuda.current_stream().cuda_stream)
+    matcher.match_bruteforce_device(dq, qs, qs, None, dt, T, 0, None, nb, *outs)
+    torch.cuda.synchronize()
+    ex.set_stream(None)
+    got = [o.cpu().numpy() for o in outs]
+    for b in range(nb):
+        ref = oracle.match_bruteforce(q[b], t)
+        for g, r in zip(got, ref):
+            assert np.array_equal(g[b], r)
 
 
 def test_bruteforce_device_batched_empty_sets_and_padded_strides(ex, matcher, oracle, form):

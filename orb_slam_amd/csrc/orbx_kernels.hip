@@ -1389,8 +1389,10 @@ __global__ __launch_bounds__(kQtBinsThreads) void k_qt_bins(FrameGeom g, CountLe
                                                  unsigned char* __restrict__ scratch)
 {
     constexpr int kNodes = 1 + 4 + 16 + 64 + 256 + 1024;      // nodes of a block over its kQtBlockDepths + 1 depths
+    constexpr int kTab = 1024;                                // pixels per axis the leaf tables below can cover
     __shared__ int s_H[kNodes];
     __shared__ unsigned long long s_Bk[kNodes];
+    __shared__ unsigned short s_tx[kTab], s_ty[kTab];
     const int level = cl.level[blockIdx.y], f = blockIdx.z, tid = threadIdx.x;
     const LevelGeom& L = g.lv[level];
     const int nIni = L.nIni, D = cl.depth[blockIdx.y], Db = qt_block_depth(D), LB = D - Db;
@@ -1404,24 +1406,64 @@ __global__ __launch_bounds__(kQtBinsThreads) void k_qt_bins(FrameGeom g, CountLe
     // the block's rectangle
     const int root = pb >> (2 * Db);
     int bx0 = (short)(int)__fmul_rn(hX, (float)root), bx1 = (short)(int)__fmul_rn(hX, (float)(root + 1)), by0 = 0, by1 = (short)L.height;
+    int bxp = 0, byp = 0;                               // the block's quadrant digits, x and y bits apart
     for (int d = 0; d < Db; d++) {
         const int dig = (pb >> (2 * (Db - 1 - d))) & 3;
         const int hx = ceil_half(bx1 - bx0), hy = ceil_half(by1 - by0);
         if (dig & 1) bx0 = (short)(bx0 + hx); else bx1 = (short)(bx0 + hx);
         if (dig & 2) by0 = (short)(by0 + hy); else by1 = (short)(by0 + hy);
+        bxp = 2 * bxp + (dig & 1);
+        byp = 2 * byp + (dig >> 1);
     }
     for (int i = tid; i < kNodes; i += kQtBinsThreads) { s_H[i] = 0; s_Bk[i] = 0ull; }
-    __syncthreads();
-    QTB_MARK(1);
     // cells whose keys (x in [cj * wCell + 3, cj * wCell + 3 + wCell), likewise y) can lie in the rectangle widened by a pixel
     const int cj0 = max(0, (bx0 - 4) / L.wCell), cj1 = min(L.nCols - 1, max(bx1 - 3, 0) / L.wCell);
     const int ci0 = max(0, (by0 - 4) / L.hCell), ci1 = min(L.nRows - 1, max(by1 - 3, 0) / L.hCell);
     const int ncj = cj1 - cj0 + 1, nci = ci1 - ci0 + 1;
     const int leaf_base = ((1 << (2 * LB)) - 1) / 3;     // first leaf entry of the block's arrays
+    // A key's quadrant digits are an x bit and a y bit per depth, and each axis is halved on its own: the x bits follow
+    // from x alone (root included), the y bits from y alone.  So the descent is made once per pixel column and pixel row
+    // the visited cells cover instead of once per key (seven dependent halvings): s_tx / s_ty hold the column's / row's
+    // bits inside the block, spread to the even / odd bit positions of the leaf number, or 0xffff when the column / row
+    // leaves the block.  Keys outside the tables (blocks wider than kTab pixels) make the descent themselves.
+    const int xlo = cj0 * L.wCell + 3, ylo = ci0 * L.hCell + 3;
+    const int nx = (ncj > 0 && nci > 0) ? min(kTab, ncj * L.wCell) : 0, ny = (ncj > 0 && nci > 0) ? min(kTab, nci * L.hCell) : 0;
+    auto spread = [](int v) { return (v & 1) | ((v & 2) << 1) | ((v & 4) << 2) | ((v & 8) << 3) | ((v & 16) << 4); };
+    for (int i = tid; i < nx + ny; i += kQtBinsThreads) {
+        const bool isx = i < nx;
+        const int p = isx ? xlo + i : ylo + (i - nx);
+        int r = 0, p0 = 0, p1 = (short)L.height;
+        if (isx) {
+            r = (int)__fdiv_rn((float)p, hX);                      // :515-519
+            r = min(max(r, 0), nIni - 1);
+            p0 = (short)(int)__fmul_rn(hX, (float)r);
+            p1 = (short)(int)__fmul_rn(hX, (float)(r + 1));
+        }
+        int bits = 0;
+        for (int d = 0; d < D; d++) {
+            const int h = ceil_half(p1 - p0);
+            const int far = p < p0 + h ? 0 : 1;
+            if (far) p0 = (short)(p0 + h); else p1 = (short)(p0 + h);
+            bits = 2 * bits + far;
+        }
+        const bool inside = isx ? (r == root && (bits >> LB) == bxp) : (bits >> LB) == byp;
+        const int sp = spread(bits & ((1 << LB) - 1));
+        if (isx) s_tx[i] = (unsigned short)(inside ? sp : 0xffff);
+        else s_ty[i - nx] = (unsigned short)(inside ? 2 * sp : 0xffff);
+    }
+    __syncthreads();
+    QTB_MARK(1);
     const int sub = tid & 7;
     const uint32_t* cands = cell_cand + (size_t)f * g.cand_per_frame + L.cand_base;
     auto add_key = [&](uint32_t u, int xc, int yc, uint32_t slot) {
         const int x = xc + (int)((u >> 8) & 0xff), y = yc + (int)(u >> 16);
+        if ((unsigned)(x - xlo) < (unsigned)nx && (unsigned)(y - ylo) < (unsigned)ny) {
+            const uint32_t t = (uint32_t)s_tx[x - xlo] | (uint32_t)s_ty[y - ylo];
+            if (t & 0x8000u) return;
+            atomicAdd(&s_H[leaf_base + (int)t], 1);
+            atomicMax(&s_Bk[leaf_base + (int)t], ((unsigned long long)(u & 0xff) << 32) | (unsigned long long)(0xFFFFFFFFu - slot));
+            return;
+        }
         int r = (int)__fdiv_rn((float)x, hX);                      // :515-519
         r = min(max(r, 0), nIni - 1);
         int x0 = (short)(int)__fmul_rn(hX, (float)r), x1 = (short)(int)__fmul_rn(hX, (float)(r + 1)), y0 = 0, y1 = (short)L.height;

@@ -1560,7 +1560,8 @@ int orbx_grid_search_device(orbx_ctx* c, const orbx_keypoint* d_kps, const uint3
 static int grid_upload(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* desc, int N, const float* qx, const float* qy,
                        const float* qr, const int32_t* qmin, const int32_t* qmax, const uint32_t* qdesc, int Q)
 {
-    if (!kps || !qx || !qy || !qr || !qmin || !qmax) return fail(c, ORBX_ERR_INVALID, "null buffer");
+    // a frame without keypoints may come as a null pointer (the data() of an empty std::vector)
+    if ((N > 0 && !kps) || !qx || !qy || !qr || !qmin || !qmax) return fail(c, ORBX_ERR_INVALID, "null buffer");
     HIPCHECK(c, hipSetDevice(c->device));
     HIPCHECK(c, finish(c));
     const size_t n = (size_t)(N > 0 ? N : 1), q = (size_t)Q;

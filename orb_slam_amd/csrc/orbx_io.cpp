@@ -186,6 +186,16 @@ void finish_node(Node& n, const std::string& body)
     collect_numbers(body, n.numbers);
 }
 
+// A number of the file as an integer of the target's range: rounded half to even and saturated, as OpenCV's reader
+// converts (cvRound + saturate_cast); a plain cast of a value outside the range is undefined.  NaN reads as 0.
+long to_int_saturated(double v, long lo, long hi)
+{
+    if (!(v == v)) return 0;
+    if (v <= (double)lo) return lo;
+    if (v >= (double)hi) return hi;
+    return std::lrint(v);
+}
+
 int keypoints_from(const Node& n, orbx_keypoint* out, int cap, int* count, const char* what)
 {
     if (!n.present) return io_fail(ORBX_ERR_INVALID, std::string("key missing: ") + what);
@@ -197,7 +207,8 @@ int keypoints_from(const Node& n, orbx_keypoint* out, int cap, int* count, const
     for (int i = 0; i < cnt; i++) {
         const double* v = &n.numbers[(size_t)i * 7];
         out[i].x = (float)v[0]; out[i].y = (float)v[1]; out[i].size = (float)v[2]; out[i].angle = (float)v[3];
-        out[i].response = (float)v[4]; out[i].octave = (int32_t)v[5]; out[i].class_id = (int32_t)v[6];
+        out[i].response = (float)v[4]; out[i].octave = (int32_t)to_int_saturated(v[5], INT32_MIN, INT32_MAX);
+        out[i].class_id = (int32_t)to_int_saturated(v[6], INT32_MIN, INT32_MAX);
     }
     return ORBX_OK;
 }
@@ -210,7 +221,7 @@ int descriptors_from(const Node& n, uint8_t* out, int cap, int count, const char
         return io_fail(ORBX_ERR_INVALID, std::string(what) + ": expected a " + std::to_string(count) + " x 32 matrix of dt u");
     if (!out) return ORBX_OK;
     if (count > cap) return io_fail(ORBX_ERR_CAPACITY, std::string(what) + ": buffer too small");
-    for (long i = 0; i < 32L * count; i++) out[i] = (uint8_t)n.numbers[(size_t)i];
+    for (long i = 0; i < 32L * count; i++) out[i] = (uint8_t)to_int_saturated(n.numbers[(size_t)i], 0, 255);
     return ORBX_OK;
 }
 

@@ -124,3 +124,33 @@ def test_extraction_output_survives_the_wire(tmp_path, oracle, euroc_left, euroc
         for f in KP_DTYPE.names:
             assert np.array_equal(a[f], b[f]), f
     assert np.array_equal(log.mDiscLeft, dl) and np.array_equal(log.mDiscRight, dr)
+
+
+def test_reader_saturates_out_of_range_numbers(tmp_path):
+    """descriptor bytes and the integer fields of a keypoint are rounded and saturated like cv::FileStorage's
+    conversions (cvRound + saturate_cast); a plain cast of such a value would be undefined"""
+    text = OPENCV_STYLE.replace("data: [ 1, 2,", "data: [ 9160, -4,").replace("600.480042", "6.00480042e2")
+    assert "9160" in text
+    p = tmp_path / "sat.yml"
+    p.write_text(text)
+    log = KeyPointLog()
+    assert log.ReadFromYAML(p)
+    assert log.mDiscLeft[0, 0] == 255 and log.mDiscLeft[0, 1] == 0 and log.mDiscLeft[0, 2] == 3
+    assert log.mvKeysLeft["x"][1] == np.float32(600.480042)
+
+
+def test_cpp_reader_on_damaged_files(tmp_path):
+    """tests/cpp/abi_sweep.cpp, detection I/O part: every prefix of a written file, 1200 files with random edits and
+    files whose declared sizes disagree with their data are read into buffers of exactly the stated capacity; the
+    reader must return (any code) and leave counts within the capacity whenever it reports success.  With
+    ORBX_CPP_DIR pointing at the build of tools/host_sanitizers.sh the same run is under AddressSanitizer and
+    UndefinedBehaviorSanitizer."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "abi_sweep")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "abi_sweep"])
+    p = subprocess.run([exe, "yaml", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    assert b"0 failed expectations" in p.stdout

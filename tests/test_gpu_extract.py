@@ -410,7 +410,7 @@ def test_cpp_host_program(oracle, euroc_left, tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "host_extract")
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "host_extract")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "host_extract"])
     raw = tmp_path / "img.raw"
@@ -440,7 +440,7 @@ def test_cpp_sharded_extractor_and_matcher(oracle, euroc_left, euroc_right, tmp_
     import subprocess
     from orb_slam_amd.synth import synthetic_batch
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "sharded_extract")
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "sharded_extract")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "sharded_extract"])
     frames = np.concatenate([np.stack([euroc_left, euroc_right]), synthetic_batch(5, 752, 480, seed0=8800)])
@@ -496,7 +496,7 @@ def test_cpp_adapter_program(euroc_left, tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "adapter_frame")
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "adapter_frame")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "adapter_frame"])
     raw = tmp_path / "img.raw"

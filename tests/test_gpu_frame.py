@@ -142,3 +142,21 @@ def test_detections_written_by_the_gpu_path_replay_bit_identically(tmp_path, eur
     assert np.array_equal(got[2], f.mvuRight[:len(kl_o)]) and np.array_equal(got[3], f.mvDepth[:len(kl_o)])
     exl.close()
     exr.close()
+
+
+@pytest.mark.gpu
+def test_cpp_abi_sweep(tmp_path):
+    """tests/cpp/abi_sweep.cpp: the host-array entry points no other C++ program reaches (candidate lists, fused grid
+    search, windowed and brute-force matching, the three stereo searches, undistortion, extraction of odd sizes) on
+    empty, tiny and ordinary sizes with every output buffer at its exact size.  Results are compared with the CPU
+    restatement in the Python tests; this program is what tools/host_sanitizers.sh runs under AddressSanitizer and
+    UndefinedBehaviorSanitizer (ORBX_CPP_DIR points at that build)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "abi_sweep")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "abi_sweep"])
+    p = subprocess.run([exe, "all", str(tmp_path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=280)
+    assert p.returncode == 0, (p.stdout.decode()[-500:], p.stderr.decode()[-3000:])
+    assert b"0 failed expectations" in p.stdout

@@ -741,7 +741,7 @@ def test_cpp_delayed_stereo_class(ex, oracle, tmp_path):
     import struct
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "stereo_delayed")
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "stereo_delayed")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "stereo_delayed"])
     rng = np.random.default_rng(12)

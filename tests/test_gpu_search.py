@@ -485,7 +485,7 @@ def test_cpp_matcher_calls(oracle, euroc_left, euroc_right, tmp_path):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = os.path.join(root, "tests", "cpp", "matcher_calls")
+    exe = os.path.join(os.environ.get("ORBX_CPP_DIR", os.path.join(root, "tests", "cpp")), "matcher_calls")
     if not os.path.exists(exe):
         subprocess.check_call(["make", "-C", os.path.dirname(exe), "matcher_calls"])
     raw, out = tmp_path / "pair.raw", tmp_path / "calls.bin"

@@ -1687,6 +1687,9 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
                 if (i < m && sub == 0) s_order[r] = s_cand[i];
             }
             __syncthreads();
+            // A level with fewer keys than features to keep can never hold N nodes (no node is empty), so every
+            // sweep splits all its candidates: no search for the split that reaches N.
+            if (total >= N) {
             const int cs = (m + NT - 1) / NT;
             const int s0 = min(tid * cs, m), s1 = min(s0 + cs, m);
             int gsum = 0;
@@ -1708,6 +1711,7 @@ __device__ __forceinline__ bool quadtree_counts_body(const FrameGeom& g, const C
             norder = min(s_var[7] + 1, m);
             for (int s_ = s0; s_ < s1; s_++) s_fl[s_order[s_]] = (unsigned char)(s_ < norder);
             __syncthreads();
+            }
             QT_STEP(2);
         }
         const int co = (norder + NT - 1) / NT;
@@ -2105,6 +2109,9 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
                 if (i < m && sub == 0) s_order[r] = s_cand[i];
             }
             __syncthreads();
+            // A level with fewer keys than features to keep can never hold N nodes (no node is empty), so every
+            // sweep splits all its candidates: no search for the split that reaches N.
+            if (n >= N) {
             // growth of |L| per split, in processing order; the splits up to and including the first that reaches N
             const int cs = (m + NT - 1) / NT;
             const int s0 = min(tid * cs, m), s1 = min(s0 + cs, m);
@@ -2127,6 +2134,7 @@ __device__ __forceinline__ void quadtree_body(const FrameGeom& g, const uint32_t
             norder = min(s_var[7] + 1, m);
             for (int s_ = s0; s_ < s1; s_++) s_fl[s_order[s_]] = (unsigned char)(s_ < norder);
             __syncthreads();
+            }
             QT_STEP(2);
         }
         // d. positions: children and expandable children of the parents before this thread's, untouched nodes before its own

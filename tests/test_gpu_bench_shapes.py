@@ -170,3 +170,18 @@ def test_bench_match_128_x_1000_x_1000():
             b = k + j * NTHREADS
             assert np.array_equal(got[0][b], oi) and np.array_equal(got[1][b], od) and np.array_equal(got[2][b], os_), b
     ex.close()
+
+
+def test_batch_beyond_four_gib():
+    """160 resident frames of 3840 x 2160 at 8000 features: the pyramid and blurred blocks pass 4 GiB, so every
+    per-frame offset must be 64-bit.  The batch repeats eight frames (whose outputs the 8-frame test above compares
+    with the oracle); every frame must reproduce the frame eight places before it bit for bit
+    (tools/big_batch_check.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "big_batch_check.py"), "160"], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=280)
+    assert p.returncode == 0, (p.stdout.decode()[-1500:], p.stderr.decode()[-1500:])
+    assert b"0 frames differ" in p.stdout

@@ -5,6 +5,7 @@
 // three bits, bit k = more than 32 of its bits 64 k .. 64 k + 63 are set; flags by index modulo small numbers; every
 // keypoint of frame 0 as a map point that projects to its own position in frame 1, and the other way round.
 // out_file: a sequence of blocks, each int32 length followed by that many int32 values (see `dump` calls below).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -14,6 +15,7 @@
 static FILE* g_out;
 static void dump(const std::vector<int32_t>& v)
 {
+    if (!g_out) return;      // the calls on cut-down feature sets below are made for their memory accesses only
     const int32_t n = (int32_t)v.size();
     std::fwrite(&n, 4, 1, g_out);
     std::fwrite(v.data(), 4, v.size(), g_out);
@@ -55,26 +57,13 @@ static orbx::ProjectedPoints points_of(const std::vector<orbx_keypoint>& k, cons
     return p;
 }
 
-int main(int argc, char** argv)
+static void calls(orbx::ORBextractor& ex, int w, int h, const std::vector<orbx_keypoint>& k1, const std::vector<uint8_t>& d1,
+                  const std::vector<orbx_keypoint>& k2, const std::vector<uint8_t>& d2)
 {
-    if (argc != 5) { std::fprintf(stderr, "usage: %s raw w h out\n", argv[0]); return 2; }
-    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
-    std::vector<uint8_t> img((size_t)w * h * 2);
-    FILE* f = std::fopen(argv[1], "rb");
-    if (!f || std::fread(img.data(), 1, img.size(), f) != img.size()) { std::fprintf(stderr, "cannot read frames\n"); return 2; }
-    std::fclose(f);
-    try {
-        orbx::ORBextractor ex(1000, 1.2f, 8, 20, 7);
-        std::vector<orbx_keypoint> k1, k2;
-        std::vector<uint8_t> d1, d2;
-        const orbx::ImageView none;
-        ex(orbx::ImageView(img.data(), w, h, (size_t)w), none, k1, d1);
-        ex(orbx::ImageView(img.data() + (size_t)w * h, w, h, (size_t)w), none, k2, d2);
         const size_t n1 = k1.size(), n2 = k2.size();
         orbx::FrameGrid grid;
         grid.mfGridElementWidthInv = 64.0f / (float)w;
         grid.mfGridElementHeightInv = 48.0f / (float)h;
-        g_out = std::fopen(argv[4], "wb");
         dump(std::vector<int32_t>{(int32_t)n1, (int32_t)n2});
         const orbx::FeatureVector fv1 = feature_vector(d1.data(), n1), fv2 = feature_vector(d2.data(), n2);
         std::vector<uint8_t> has1(n1), has2(n2), held1(n1), held2(n2), st1(n1), st2(n2);
@@ -137,7 +126,37 @@ int main(int argc, char** argv)
         dump1(stopped);
         dump(m2);
         dump(s2);
+}
+
+int main(int argc, char** argv)
+{
+    if (argc != 5) { std::fprintf(stderr, "usage: %s raw w h out\n", argv[0]); return 2; }
+    const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+    std::vector<uint8_t> img((size_t)w * h * 2);
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(img.data(), 1, img.size(), f) != img.size()) { std::fprintf(stderr, "cannot read frames\n"); return 2; }
+    std::fclose(f);
+    try {
+        orbx::ORBextractor ex(1000, 1.2f, 8, 20, 7);
+        std::vector<orbx_keypoint> k1, k2;
+        std::vector<uint8_t> d1, d2;
+        const orbx::ImageView none;
+        ex(orbx::ImageView(img.data(), w, h, (size_t)w), none, k1, d1);
+        ex(orbx::ImageView(img.data() + (size_t)w * h, w, h, (size_t)w), none, k2, d2);
+        g_out = std::fopen(argv[4], "wb");
+        if (!g_out) { std::fprintf(stderr, "cannot write %s\n", argv[4]); return 2; }
+        calls(ex, w, h, k1, d1, k2, d2);
         std::fclose(g_out);
+        g_out = nullptr;
+        // the same calls on empty, one-element and lopsided feature sets (nothing is dumped: under the sanitizers of
+        // tools/host_sanitizers.sh every access outside a buffer is a report)
+        const size_t cuts[][2] = {{0, 0}, {0, 5}, {5, 0}, {1, 1}, {3, 700}, {700, 2}};
+        for (const auto& c : cuts) {
+            const size_t c1 = std::min(c[0], k1.size()), c2 = std::min(c[1], k2.size());
+            calls(ex, w, h, std::vector<orbx_keypoint>(k1.begin(), k1.begin() + c1), std::vector<uint8_t>(d1.begin(), d1.begin() + 32 * c1),
+                  std::vector<orbx_keypoint>(k2.begin(), k2.begin() + c2), std::vector<uint8_t>(d2.begin(), d2.begin() + 32 * c2));
+        }
+        const size_t n1 = k1.size(), n2 = k2.size();
         std::printf("matcher calls ok: %zu and %zu keypoints\n", n1, n2);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "%s\n", e.what());

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 #include "../../include/orbx.h"
@@ -2711,6 +2712,14 @@ int quadtree_prepare(int max_nodes)
     size_t lds = quadtree_lds_bytes(max_nodes);
     if (lds > 160 * 1024) return -1;
     if (lds > 64 * 1024) {
+        // The opt-in for more than 64 KB of dynamic LDS belongs to the kernel on a device, not to a context: it is only
+        // ever raised, so that a second context with a smaller quadtree cannot take away what the first one was granted.
+        static std::mutex mu;
+        static size_t granted[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 0 && dev < 64 && lds <= granted[dev]) return 0;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
@@ -2720,6 +2729,7 @@ int quadtree_prepare(int max_nodes)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_quadtree_mid),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
+        if (dev >= 0 && dev < 64) granted[dev] = lds;
     }
     return 0;
 }

@@ -703,3 +703,27 @@ def test_batch_pyramid_borders_on_odd_sizes(w, h, nlevels, scale):
         _assert_features(res[i][0], res[i][1], kps_o, desc_o)
         assert np.array_equal(res[i][1], desc_o)
     ex.close()
+
+
+@pytest.mark.gpu
+def test_two_extractors_with_large_feature_counts_take_turns():
+    """Two contexts on one device whose quadtrees each need more than 64 KB of LDS, of different sizes (8000 and
+    6000 features): the opt-in for large dynamic LDS belongs to the kernel, not to a context, so the second
+    context's smaller request must not undo the first one's.  A, B, A again: every call succeeds and A repeats
+    its result."""
+    from orb_slam_amd import ORBextractor
+    img = synthetic_frame(1600, 1200, 31, nrect=1500)
+    a = ORBextractor(8000, 1.2, 8, 20, 7)
+    ka1, da1 = a(img)
+    b = ORBextractor(6000, 1.2, 8, 20, 7)
+    kb, db = b(img)
+    ka2, da2 = a(img)
+    kb2, db2 = b(img)
+    assert len(ka1) > 6000 and len(kb) > 4500
+    assert np.array_equal(ka1, ka2) and np.array_equal(da1, da2)
+    assert np.array_equal(kb, kb2) and np.array_equal(db, db2)
+    orc = Oracle(6000, 1.2, 8, 20, 7)
+    ko, do = orc.extract(img, literal=False, cap=8000)
+    _assert_features(kb, db, ko, do)
+    a.close()
+    b.close()

@@ -1812,6 +1812,17 @@ static int grid_lists(orbx_ctx* c, const orbx_keypoint* kps, const uint32_t* des
 }
 
 // ORBmatcher::ComputeThreeMaxima, src/ORBmatcher.cc:1723-1764
+// Bin of the rotation histogram (src/ORBmatcher.cc:590-594): round(rot * factor), bin HISTO_LENGTH wraps to 0; the reference
+// asserts the range.  False for an angle difference that is not a number or far outside (a conversion of such a value
+// to int is undefined), and for a bin outside the histogram.
+static bool rotation_bin(float scaled, int nbins, int& bin)
+{
+    if (!(scaled > -1.0e6f && scaled < 1.0e6f)) return false;
+    bin = (int)roundf(scaled);
+    if (bin == nbins) bin = 0;
+    return bin >= 0 && bin < nbins;
+}
+
 static void three_maxima(const std::vector<int32_t>* histo, int L, int& ind1, int& ind2, int& ind3)
 {
     int max1 = 0, max2 = 0, max3 = 0;
@@ -1883,9 +1894,8 @@ int orbx_search_for_initialization(orbx_ctx* c, const orbx_keypoint* k1, const u
             if (check_orientation) {                                          // :588-598
                 float rot = k1[i1].angle - k2[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
-                int bin = (int)roundf(rot * factor);
-                if (bin == kHisto) bin = 0;
-                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");   // the reference asserts
+                int bin = 0;
+                if (!rotation_bin(rot * factor, kHisto, bin)) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
                 rotHist[bin].push_back(i1);
             }
         }
@@ -2181,9 +2191,8 @@ static int search_by_bow(orbx_ctx* c, const orbx_keypoint* k1, const uint32_t* d
             if (check_orientation) {
                 float rot = k1[i1].angle - k2[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
-                int bin = (int)roundf(rot * (1.0f / kHisto));
-                if (bin == kHisto) bin = 0;
-                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");   // the reference asserts
+                int bin = 0;
+                if (!rotation_bin(rot * (1.0f / kHisto), kHisto, bin)) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
                 rotHist[bin].push_back(keyframes ? i1 : bestIdx2);
             }
             nm++;
@@ -2295,9 +2304,8 @@ static int projected_points_search(orbx_ctx* c, const orbx_keypoint* kps, const 
             if (check_orientation) {                                          // :1554-1564
                 float rot = lp_angle[i] - kps[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
-                int bin = (int)roundf(rot * factor);
-                if (bin == kHisto) bin = 0;
-                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
+                int bin = 0;
+                if (!rotation_bin(rot * factor, kHisto, bin)) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
                 rotHist[bin].push_back(bestIdx2);
             }
         }
@@ -2584,9 +2592,8 @@ int orbx_search_for_triangulation(orbx_ctx* c, const orbx_keypoint* k1, const ui
             if (check_orientation) {
                 float rot = k1[i1].angle - k2[bestIdx2].angle;
                 if (rot < 0.0) rot += 360.0f;
-                int bin = (int)roundf(rot * (1.0f / kHisto));
-                if (bin == kHisto) bin = 0;
-                if (bin < 0 || bin >= kHisto) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
+                int bin = 0;
+                if (!rotation_bin(rot * (1.0f / kHisto), kHisto, bin)) return fail(c, ORBX_ERR_INVALID, "keypoint angles outside [0, 360)");
                 rotHist[bin].push_back(i1);
             }
         }
